@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: 16K-point frames/s through window + IIR + FFT (+ magnitude).
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by the driver with
+torch.distributed.run, one rank per GPU).  One step = one pass of the fused float chain over one
+batch of 4096 synthetic frames resident in HBM (BASELINE.json configs[2], the configuration the
+metric is quoted on).  Frames are independent, so ranks shard the batch dimension with no
+data-path collective (weak scaling: 4096 frames per GPU); the only inter-rank traffic is the
+timing barrier / max-reduce, done over gloo on the host.
+
+Prints ONE JSON line on rank 0 with the driver's keys plus ``roofline`` and ``cpu_baseline``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N = 16384
+BYTES_PER_FRAME_F32 = 2 * N * 4          # read 64 KiB + write 64 KiB magnitudes
+BYTES_PER_FRAME_Q15 = N * 2 + N * 4      # read 32 KiB + write 64 KiB IQ
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_host(B: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    n = np.arange(N)
+    fb = rng.uniform(0.01, 0.45, size=B)
+    return (0.8 * np.sin(2 * np.pi * fb[:, None] * n[None, :]) + 0.05 * rng.standard_normal((B, N))).astype(np.float32)
+
+
+def _cpu_slice(args):
+    x, sos, hann = args
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    orc.cpu_baseline_chain(x, sos, hann)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(sos: np.ndarray) -> dict:
+    """scipy/numpy chain on a bounded sample, single thread and all cores.
+    Runs before anything touches the GPU (it forks a worker pool)."""
+    from multiprocessing import get_context
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    hann = orc.hann_f64().astype(np.float32)
+    x1 = synth_host(256, seed=1)
+    orc.cpu_baseline_chain(x1[:8], sos, hann)                # warm-up
+    t0 = time.perf_counter()
+    orc.cpu_baseline_chain(x1, sos, hann)
+    t_single = time.perf_counter() - t0
+    fps_single = x1.shape[0] / t_single
+    # all cores: about 10 s of aggregate CPU work, one 64-frame slice per task
+    per_worker = max(64, int(fps_single * 10.0 / 64) * 64 // max(cores, 1) // 64 * 64)
+    nslices = cores * max(1, per_worker // 64)
+    xs = synth_host(64, seed=2)
+    with get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_slice, [(xs, sos, hann)] * cores)      # warm-up
+        t0 = time.perf_counter()
+        pool.map(_cpu_slice, [(xs, sos, hann)] * nslices)
+        t_all = time.perf_counter() - t0
+    fps_all = nslices * 64 / t_all
+    return {"value": round(fps_all, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_frames_per_s": round(fps_single, 1),
+            "sample": f"np.abs(np.fft.rfft(scipy.signal.sosfilt(sos, x*hann))) float32 in / float64 inside; "
+                      f"single thread on 256 frames, {cores}-process pool on {nslices * 64} frames "
+                      f"(64-frame slices), same synthetic distribution as the GPU run"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time the bypass (config 2) and Q15 (config 4) paths")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]    # 12th-order Butterworth, wn = 0.2
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(sos)                      # before any GPU initialisation (forks)
+
+    import torch
+    import torch.distributed as dist
+    from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain
+
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ch = SpectrumChain(local_rank)                   # raises if the HIP extension is missing
+    ch.load_sos(sos)
+    ch.set_filter_mode(0xA1)
+
+    B = a.batch
+    gen = torch.Generator(device=dev).manual_seed(10 + rank)
+    n = torch.arange(N, device=dev, dtype=torch.float32)
+    fb = torch.rand(B, 1, generator=gen, device=dev) * 0.44 + 0.01
+    x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, N, generator=gen, device=dev)).contiguous()
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        ch.process_f32(x, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ch.process_f32(x, out=out)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+        dist.barrier()
+
+    # per-launch kernel time with HIP events on the launch stream (torch's current stream is the one
+    # handed to the ABI), median over the same number of steps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for e0, e1 in evs:
+        e0.record()
+        ch.process_f32(x, out=out)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    k_avg_ms = float(np.mean(k_ms))
+    k_med_ms = float(k_ms[len(k_ms) // 2])
+
+    extras = {}
+    if a.extras and rank == 0:
+        def time_it(fn, steps):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t) / steps
+        ch.set_filter_mode(0xB1)
+        x256 = x[:256].contiguous()
+        o256 = out[:256]
+        dt = time_it(lambda: ch.process_f32(x256, out=o256), 50)
+        extras["config2_bypass_b256"] = {"frames_per_s": 256 / dt, "GBps": 256 * BYTES_PER_FRAME_F32 / dt / 1e9}
+        dt = time_it(lambda: ch.process_f32(x, out=out), a.steps)
+        extras["bypass_b4096"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
+        xq = torch.randint(-2048, 2048, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+        oq = torch.empty((B, N, 2), dtype=torch.int16, device=dev)
+        ch.reserve(B)
+        for name, cmd in (("config4_q15_default_iir", 0x00), ("q15_bypass", 0xB1)):
+            ch.set_filter_mode(cmd)
+            dt = time_it(lambda: ch.process_q15(xq, out=oq), 5)
+            extras[name] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+
+    if rank == 0:
+        frames = B * world * a.steps
+        achieved = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "16K-pt frames/sec (window+IIR+FFT), batch=4096",
+            "value": round(frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"batch={B}x16K fp32 frames per GPU, Hann + 6-biquad IIR (12th-order Butterworth "
+                                   f"wn=0.2) + 16K FFT + magnitude, all 16384 bins written (BASELINE.json configs[2])",
+                       "frames_per_gpu": B, "sharding": "batch, independent per-GPU streams, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "chain_f32_kernel<IIR,MAG_FULL>", "kernel_ms_avg": round(k_avg_ms, 4),
+                         "kernel_ms_median": round(k_med_ms, 4),
+                         "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        if extras:
+            line["extras"] = extras
+        print(json.dumps(line), flush=True)
+    ch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

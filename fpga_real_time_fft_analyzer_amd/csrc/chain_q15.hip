@@ -1,0 +1,294 @@
+// chain_q15.hip -- bit-exact integer signal path for gfx950 (MI355X).
+//
+//   sa_filter kernel : Q15 window (new/hann8192.vhd:36-39) + 6-stage integer biquad cascade
+//                      (new/filter_iir_cust.vhd:96-117, new/filter_iir12_cust.vhd:68-240).
+//                      The recursion is non-linear (per-product truncation, 16-bit wrap), so a
+//                      frame cannot be cut in time; the parallelism is batch x section: 8 lanes
+//                      per frame run the six sections as a systolic pipeline (lane s works on
+//                      sample n-s), neighbours hand samples over with a wave shuffle.
+//   sa_fft kernel    : SA-FXFFT-1, the fixed-point FFT that stands where ip/xfft_0 stands
+//                      (radix-4 DIF, >>2 per stage, Q15 twiddles, truncation).  One 256-thread
+//                      workgroup per frame, data in LDS as packed (re,im) int16 pairs, Stockham
+//                      (autosort) addressing so the result is in natural order; the arithmetic per
+//                      butterfly is exactly oracle/specan_oracle.c:or_fxfft16k.
+#include "sa_common.hpp"
+#include "../../include/specan.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ window
+// new/hann8192.vhd:36-39: out = resize16(product(31..15) + product(14))
+__device__ __forceinline__ int win_rtl(int x, int c)
+{
+    const int p = x * c;
+    const int r = (p >> 15) + ((p >> 14) & 1);
+    const unsigned r17 = (unsigned)r & 0x1FFFFu;
+    const unsigned o = (r17 & 0x7FFFu) | (((r17 >> 16) & 1u) << 15);
+    return (int)(short)o;
+}
+
+// SURVEY quirk Q2 alternative: ROM + 32768 as unsigned Q16 Hann, round half up
+__device__ __forceinline__ int win_u16(int x, int c)
+{
+    const int w = c + 32768;
+    const long long p = (long long)x * w + 32768;
+    return (int)(short)(p >> 16);
+}
+
+__device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ int lo16(unsigned v) { return (int)(short)(v & 0xFFFFu); }
+__device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
+
+// ------------------------------------------------------------------------------------------ IIR
+constexpr int kTile = 256;            // samples per staging tile
+constexpr int kRowPitch = kTile + 2;  // int16 elements; +2 breaks the 8-row bank alignment
+constexpr int kFramesPerWave = 8;
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restrict__ in,
+                                                         int16_t *__restrict__ out, int batch, SaQ15Params prm,
+                                                         const int16_t *__restrict__ rom)
+{
+    __shared__ int16_t tin[kFramesPerWave][kRowPitch];
+    __shared__ int16_t tout[kFramesPerWave][kRowPitch];
+    const int lane = threadIdx.x;
+    const int fr = lane >> 3;           // frame slot in this wave
+    const int sec = lane & 7;           // section index (6,7 idle)
+    const int f0 = blockIdx.x * kFramesPerWave;
+    const bool do_iir = prm.filter != SA_FILTER_NONE;
+
+    // per-lane coefficients
+    int cB0 = 0, cB1 = 0, cB2 = 0, cA0 = 0, cA1 = 0;      // q7 (RTL port names)
+    int wb0 = 0, wb1 = 0, wb2 = 0, wa1 = 0, wa2 = 0;      // q14 wide
+    bool active = sec < 6;
+    if constexpr (WIDE) {
+        active = sec < prm.nsec_wide;
+        if (active) {
+            const int16_t *c = &prm.sos_q14[sec * 6];
+            wb0 = c[0]; wb1 = c[1]; wb2 = c[2]; wa1 = c[4]; wa2 = c[5];
+        }
+    } else {
+        const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];
+        cB0 = c[0]; cB1 = c[1]; cB2 = c[2]; cA0 = c[3]; cA1 = c[4];
+    }
+    const int last_sec = WIDE ? (prm.nsec_wide - 1) : 5;
+    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;                   // section state, zero at frame start
+
+    for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
+        // ---- stage in: 8 rows x 256 samples, 16 B per lane, window applied on the way
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 2 * i + (lane >> 5);
+            const int col = (lane & 31) * 8;
+            const int f = f0 + row;
+            uint4 xv = make_uint4(0, 0, 0, 0);
+            if (f < batch) xv = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
+            const uint4 cv = *reinterpret_cast<const uint4 *>(rom + n0 + col);
+            const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int a, b;
+                if (prm.win_mode == SA_WIN_RTL_SIGNED) {
+                    a = win_rtl(lo16(xs[k]), lo16(cs[k]));
+                    b = win_rtl(hi16(xs[k]), hi16(cs[k]));
+                } else {
+                    a = win_u16(lo16(xs[k]), lo16(cs[k]));
+                    b = win_u16(hi16(xs[k]), hi16(cs[k]));
+                }
+                *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
+            }
+        }
+        __syncthreads();
+        if (do_iir) {
+            // ---- systolic run over the tile: step tau, lane `sec` handles local sample tau - sec
+            int yprev = 0;     // this lane's output of the previous step
+            for (int tau = 0; tau < kTile + 7; ++tau) {
+                const int up = __shfl_up(yprev, 1, 64);          // neighbour section's last output
+                const int i = tau - sec;
+                int x = up;
+                if (sec == 0 && i < kTile) x = tin[fr][i < 0 ? 0 : i];
+                int y = 0;
+                if (active && i >= 0 && i < kTile) {
+                    if constexpr (WIDE) {
+                        long long acc = (long long)wb0 * x + (long long)wb1 * x1 + (long long)wb2 * x2 -
+                                        (long long)wa1 * y1 - (long long)wa2 * y2;
+                        acc = (acc + 8192) >> 14;
+                        acc = acc > 32767 ? 32767 : (acc < -32768 ? -32768 : acc);
+                        y = (int)acc;
+                    } else {
+                        // B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7,
+                        // sum taken modulo 2^16 (wrapping each term first gives the same residue)
+                        const int acc = ((x * cB2) >> 7) + ((x1 * cB1) >> 7) + ((x2 * cB0) >> 7) -
+                                        ((y2 * cA0) >> 7) - ((y1 * cA1) >> 7);
+                        y = (int)(short)acc;
+                    }
+                    x2 = x1; x1 = x;
+                    y2 = y1; y1 = y;
+                    if (sec == last_sec) tout[fr][i] = (int16_t)y;
+                }
+                yprev = y;
+            }
+        }
+        __syncthreads();
+        // ---- stage out
+        int16_t (*src)[kRowPitch] = do_iir ? tout : tin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 2 * i + (lane >> 5);
+            const int col = (lane & 31) * 8;
+            const int f = f0 + row;
+            uint4 ov;
+            ov.x = *reinterpret_cast<unsigned *>(&src[row][col + 0]);
+            ov.y = *reinterpret_cast<unsigned *>(&src[row][col + 2]);
+            ov.z = *reinterpret_cast<unsigned *>(&src[row][col + 4]);
+            ov.w = *reinterpret_cast<unsigned *>(&src[row][col + 6]);
+            if (f < batch) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ FFT
+constexpr int kFftThreads = 256;
+
+__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+
+// y = sat16((u * w) >> 15), truncation; e == 0 is an exact pass-through (SA-FXFFT-1)
+__device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool unity)
+{
+    if (unity) return pack2(sat16(ur), sat16(ui));
+    const int wr = lo16(w), wi = hi16(w);
+    const int pr = (ur * wr - ui * wi) >> 15;
+    const int pi = (ur * wi + ui * wr) >> 15;
+    return pack2(sat16(pr), sat16(pi));
+}
+
+template <bool WINDOW>
+__global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
+                                                                  int16_t *__restrict__ out_iq, int batch,
+                                                                  SaQ15Params prm, const int16_t *__restrict__ rom,
+                                                                  const unsigned *__restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+    unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
+    const int t = threadIdx.x;
+
+    for (int f = blockIdx.x; f < batch; f += gridDim.x) {
+        // ---- load: 8 samples per 16-byte read, optional window, imag = 0 (new/command_control.vhd:123)
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS);
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(rom);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int u = t + 256 * i;
+            const uint4 xv = x4[u];
+            unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            int s[8];
+            if constexpr (WINDOW) {
+                const uint4 cv = c4[u];
+                const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (prm.win_mode == SA_WIN_RTL_SIGNED) {
+                        s[2 * k] = win_rtl(lo16(xs[k]), lo16(cs[k]));
+                        s[2 * k + 1] = win_rtl(hi16(xs[k]), hi16(cs[k]));
+                    } else {
+                        s[2 * k] = win_u16(lo16(xs[k]), lo16(cs[k]));
+                        s[2 * k + 1] = win_u16(hi16(xs[k]), hi16(cs[k]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s[2 * k] = lo16(xs[k]);
+                    s[2 * k + 1] = hi16(xs[k]);
+                }
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(buf + 8 * u);
+            dst[0] = make_uint4(pack2(s[0], 0), pack2(s[1], 0), pack2(s[2], 0), pack2(s[3], 0));
+            dst[1] = make_uint4(pack2(s[4], 0), pack2(s[5], 0), pack2(s[6], 0), pack2(s[7], 0));
+        }
+        __syncthreads();
+
+        // ---- 7 radix-4 DIF stages, Stockham addressing:
+        //   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
+        //   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
+        //   output i' at (j' << (2s+2)) | (i' << 2s) | kappa; twiddle exponent i' * j' * 4^s.
+        for (int s = 0; s < 7; ++s) {
+            const int sh = 2 * s;
+            unsigned v[16][4];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int bf = t + 256 * u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[u][i] = buf[bf + 4096 * i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int bf = t + 256 * u;
+                const int jp = bf >> sh;
+                const int kap = bf & ((1 << sh) - 1);
+                const int ar = lo16(v[u][0]), ai = hi16(v[u][0]);
+                const int br = lo16(v[u][1]), bi = hi16(v[u][1]);
+                const int cr = lo16(v[u][2]), ci = hi16(v[u][2]);
+                const int dr = lo16(v[u][3]), di = hi16(v[u][3]);
+                const int t0r = ar + br + cr + dr, t0i = ai + bi + ci + di;
+                const int t1r = ar + bi - cr - di, t1i = ai - br - ci + dr;
+                const int t2r = ar - br + cr - dr, t2i = ai - bi + ci - di;
+                const int t3r = ar - bi - cr + di, t3i = ai + br - ci - dr;
+                const int e1 = jp << sh;                       // exponent of W_N for i' = 1
+                const bool unity = (e1 == 0);
+                const unsigned w1 = tw[e1], w2 = tw[2 * e1], w3 = tw[3 * e1];
+                const int ob = (jp << (sh + 2)) | kap;
+                buf[ob] = pack2(sat16(t0r >> 2), sat16(t0i >> 2));
+                buf[ob + (1 << sh)] = fx_twiddle(t1r >> 2, t1i >> 2, w1, unity);
+                buf[ob + (2 << sh)] = fx_twiddle(t2r >> 2, t2i >> 2, w2, unity);
+                buf[ob + (3 << sh)] = fx_twiddle(t3r >> 2, t3i >> 2, w3, unity);
+            }
+            __syncthreads();
+        }
+
+        // ---- natural-order frame out: [16384] x (re, im) int16 = 65536 bytes (imp/sequ2.vhd:153)
+        uint4 *o4 = reinterpret_cast<uint4 *>(out_iq + (size_t)f * SA_NPTS * 2);
+        const uint4 *b4 = reinterpret_cast<const uint4 *>(buf);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o4[t + 256 * i] = b4[t + 256 * i];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
+                                const SaQ15Tables &t, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
+    if (p.filter == SA_FILTER_WIDE)
+        hipLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
+    else
+        hipLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
+    return hipGetLastError();
+}
+
+hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
+                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    const dim3 grid(batch), block(kFftThreads);
+    const int lds = SA_NPTS * 4;
+    hipError_t e;
+    if (apply_window) {
+        auto k = fft_q15_kernel<true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
+    } else {
+        auto k = fft_q15_kernel<false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,540 @@
+// specan_abi.cpp -- host side of the C ABI declared in include/specan.h.
+//
+// Owns: the opaque handle, device tables (window, twiddles, IIR plan), the Q15 workspace and the
+// command-byte state machine that mirrors new/rx_filter_coeff.vhd + new/command_control.vhd.
+// Never touches caller tensors except through the pointers given to the process calls, never
+// falls back to CPU compute.
+#include "../../include/specan.h"
+#include "sa_common.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+// imp/filter_pkg.vhd:54-68, wire order B0,B1,B2,A0,A1,A2 per set (ALPHA then BETA)
+const int8_t kDefaultQ7[12] = {-14, 0, 14, 107, 21, 127, -15, 0, 15, 107, -21, 127};
+
+struct Mat2 {
+    double a, b, c, d;
+};
+inline Mat2 mul(const Mat2 &x, const Mat2 &y)
+{
+    return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+
+// Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
+void build_plan(const double *sos, int nsec, SaIirPlan *plan)
+{
+    std::memset(plan, 0, sizeof(*plan));
+    plan->nsec = nsec;
+    for (int s = 0; s < nsec; ++s) {
+        const double *r = sos + 6 * s;
+        const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
+        SaIirSecPlan &sp = plan->sec[s];
+        sp.c[0] = (float)b0; sp.c[1] = (float)b1; sp.c[2] = (float)b2; sp.c[3] = (float)a1; sp.c[4] = (float)a2;
+        const Mat2 A = {-a1, 1.0, -a2, 0.0};
+        double v0 = b1 - a1 * b0, v1 = b2 - a2 * b0;      // Bv
+        for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[:, j] = A^(63-j) Bv
+            sp.m[0][j] = (float)v0;
+            sp.m[1][j] = (float)v1;
+            const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
+            v0 = n0; v1 = n1;
+        }
+        Mat2 P = {1, 0, 0, 1};
+        for (int i = 0; i < SA_CHUNK; ++i) P = mul(P, A);   // P = A^64
+        Mat2 pw = {1, 0, 0, 1};
+        for (int l = 0; l < 64; ++l) {                      // ppow[l] = P^l
+            sp.ppow[l][0] = (float)pw.a; sp.ppow[l][1] = (float)pw.b;
+            sp.ppow[l][2] = (float)pw.c; sp.ppow[l][3] = (float)pw.d;
+            pw = mul(pw, P);
+        }
+        sp.p64[0] = (float)pw.a; sp.p64[1] = (float)pw.b; sp.p64[2] = (float)pw.c; sp.p64[3] = (float)pw.d;
+        Mat2 q = P;
+        for (int i = 0; i < 6; ++i) {                       // plev[i] = P^(2^i)
+            sp.plev[i][0] = (float)q.a; sp.plev[i][1] = (float)q.b;
+            sp.plev[i][2] = (float)q.c; sp.plev[i][3] = (float)q.d;
+            q = mul(q, q);
+        }
+    }
+}
+
+// The RTL taps as real numbers: y = (B2 x + B1 x1 + B0 x2 - A0 y2 - A1 y1)/128
+// => scipy row [B2,B1,B0, 128, A1, A0] / 128; stages alternate set 0 / set 1 (filter_iir12_cust.vhd:68-240).
+void sos_from_q7(const int8_t *c12, double *sos /*[6][6]*/)
+{
+    for (int k = 0; k < 6; ++k) {
+        const int8_t *c = c12 + ((k & 1) ? 6 : 0);
+        double *r = sos + 6 * k;
+        r[0] = c[2] / 128.0; r[1] = c[1] / 128.0; r[2] = c[0] / 128.0;
+        r[3] = 1.0; r[4] = c[4] / 128.0; r[5] = c[3] / 128.0;
+    }
+}
+
+}  // namespace
+
+struct sa_handle {
+    int device = 0;
+    std::string err;
+    uint8_t filter_mode = SA_FILTER_NONE;
+    int8_t c12_custom[12] = {0};
+    int win_mode_q15 = SA_WIN_RTL_SIGNED;
+    int16_t sos_q14[SA_MAXSEC * 6] = {0};
+    int nsec_q14 = 0;
+    // UART byte-stream state (new/rx_filter_coeff.vhd:41-66)
+    int rx_count = -1;            // -1 = IDLE, 0..11 = ACQUIRE
+    int8_t rx_buf[12] = {0};
+    // host tables
+    std::vector<int16_t> rom;
+    SaIirPlan plan_default{}, plan_custom{};
+    // device tables
+    float *d_win_half = nullptr;
+    float2 *d_twA = nullptr, *d_twB = nullptr, *d_twP = nullptr;
+    SaIirPlan *d_plan_default = nullptr, *d_plan_custom = nullptr;
+    int16_t *d_rom = nullptr;
+    uint32_t *d_twq = nullptr;
+    int16_t *d_work = nullptr;
+    int work_frames = 0;
+};
+
+namespace {
+
+int fail(sa_handle *h, int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[256];
+    if (e != hipSuccess)
+        std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        std::snprintf(buf, sizeof buf, "%s", what);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define SA_HIP(h, call)                                          \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return fail((h), SA_EHIP, #call, e_); \
+    } while (0)
+
+int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
+{
+    // Table updates are rare control-plane events: a full device sync makes them trivially ordered
+    // against every process call issued before and after.
+    SA_HIP(h, hipSetDevice(h->device));
+    SA_HIP(h, hipDeviceSynchronize());
+    SA_HIP(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+void default_window_f64(std::vector<double> &w)
+{
+    w.resize(SA_NPTS);
+    for (int i = 0; i < SA_NPTS; ++i)   // scripts/hann_coeff.py:3-4
+        w[i] = 0.5 * (1.0 - std::cos(2.0 * M_PI * (double)i / (double)(SA_NPTS - 1)));
+}
+
+void default_rom(std::vector<int16_t> &rom)
+{
+    std::vector<double> w;
+    default_window_f64(w);
+    rom.resize(SA_NPTS);
+    for (int i = 0; i < SA_NPTS; ++i) {   // scripts/hann_coeff.py:5 (rint, int16 wrap: quirk Q1)
+        const double r = std::rint((w[i] - 0.5) * 65536.0);
+        rom[i] = (int16_t)(uint16_t)((int32_t)r & 0xFFFF);
+    }
+}
+
+int set_window_f32_from(sa_handle *h, const float *w)
+{
+    std::vector<float> half(SA_NPTS);
+    for (int i = 0; i < SA_NPTS; ++i) half[i] = 0.5f * w[i];   // exact; undone by the split step
+    return upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+}
+
+int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
+{
+    build_plan(sos_norm, nsec, &h->plan_custom);
+    return upload(h, h->d_plan_custom, &h->plan_custom, sizeof(SaIirPlan));
+}
+
+}  // namespace
+
+extern "C" {
+
+int sa_abi_version(void) { return SA_ABI_VERSION; }
+
+const char *sa_last_error(const sa_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sa_create(int device, sa_handle **out)
+{
+    if (!out) return fail(nullptr, SA_EINVAL, "sa_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SA_EHIP, "sa_create: no usable HIP device (this library has no CPU fallback)", e);
+    if (device < 0 || device >= ndev) return fail(nullptr, SA_EINVAL, "sa_create: device index out of range");
+    sa_handle *h = new (std::nothrow) sa_handle();
+    if (!h) return fail(nullptr, SA_ENOMEM, "sa_create: out of host memory");
+    h->device = device;
+#define SA_HIPC(call)                                                      \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) {                                            \
+            fail(nullptr, SA_EHIP, #call, e_);                             \
+            sa_destroy(h);                                                 \
+            return SA_EHIP;                                                \
+        }                                                                  \
+    } while (0)
+    SA_HIPC(hipSetDevice(device));
+    SA_HIPC(hipMalloc(&h->d_win_half, sizeof(float) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_twA, sizeof(float2) * 32 * 256));
+    SA_HIPC(hipMalloc(&h->d_twB, sizeof(float2) * 16 * 16));
+    SA_HIPC(hipMalloc(&h->d_twP, sizeof(float2) * 4097));
+    SA_HIPC(hipMalloc(&h->d_plan_default, sizeof(SaIirPlan)));
+    SA_HIPC(hipMalloc(&h->d_plan_custom, sizeof(SaIirPlan)));
+    SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint32_t) * SA_NPTS));
+
+    // float tables
+    {
+        std::vector<double> w;
+        default_window_f64(w);
+        std::vector<float> half(SA_NPTS);
+        for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * w[i]);
+        SA_HIPC(hipMemcpy(h->d_win_half, half.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
+        std::vector<float2> ta(32 * 256), tb(16 * 16), tp(4097);
+        for (int k1 = 0; k1 < 32; ++k1)
+            for (int m2 = 0; m2 < 256; ++m2) {
+                const double ang = -2.0 * M_PI * (double)(k1 * m2) / 8192.0;
+                ta[k1 * 256 + m2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        for (int c = 0; c < 16; ++c)
+            for (int b = 0; b < 16; ++b) {
+                const double ang = -2.0 * M_PI * (double)(c * b) / 256.0;
+                tb[c * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        for (int k = 0; k <= 4096; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / 16384.0;
+            tp[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        SA_HIPC(hipMemcpy(h->d_twA, ta.data(), sizeof(float2) * ta.size(), hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float2) * tb.size(), hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twP, tp.data(), sizeof(float2) * tp.size(), hipMemcpyHostToDevice));
+    }
+    // IIR plans: default = the fixed ALPHA/BETA cascade as real taps; custom = cleared coefficients
+    {
+        double sos[36];
+        sos_from_q7(kDefaultQ7, sos);
+        build_plan(sos, 6, &h->plan_default);
+        SA_HIPC(hipMemcpy(h->d_plan_default, &h->plan_default, sizeof(SaIirPlan), hipMemcpyHostToDevice));
+        sos_from_q7(h->c12_custom, sos);
+        build_plan(sos, 6, &h->plan_custom);
+        SA_HIPC(hipMemcpy(h->d_plan_custom, &h->plan_custom, sizeof(SaIirPlan), hipMemcpyHostToDevice));
+    }
+    // integer tables
+    {
+        default_rom(h->rom);
+        SA_HIPC(hipMemcpy(h->d_rom, h->rom.data(), sizeof(int16_t) * SA_NPTS, hipMemcpyHostToDevice));
+        std::vector<uint32_t> tq(SA_NPTS);
+        for (int m = 0; m < SA_NPTS; ++m) {   // SA-FXFFT-1 twiddles: clamp16(rint(32768 cos)), clamp16(rint(-32768 sin))
+            const double a = 2.0 * M_PI * (double)m / (double)SA_NPTS;
+            long wr = std::lrint(32768.0 * std::cos(a)), wi = std::lrint(-32768.0 * std::sin(a));
+            wr = wr > 32767 ? 32767 : (wr < -32768 ? -32768 : wr);
+            wi = wi > 32767 ? 32767 : (wi < -32768 ? -32768 : wi);
+            tq[m] = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
+        }
+        SA_HIPC(hipMemcpy(h->d_twq, tq.data(), sizeof(uint32_t) * SA_NPTS, hipMemcpyHostToDevice));
+    }
+#undef SA_HIPC
+    *out = h;
+    return SA_OK;
+}
+
+int sa_destroy(sa_handle *h)
+{
+    if (!h) return SA_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->d_win_half);
+    (void)hipFree(h->d_twA);
+    (void)hipFree(h->d_twB);
+    (void)hipFree(h->d_twP);
+    (void)hipFree(h->d_plan_default);
+    (void)hipFree(h->d_plan_custom);
+    (void)hipFree(h->d_rom);
+    (void)hipFree(h->d_twq);
+    (void)hipFree(h->d_work);
+    delete h;
+    return SA_OK;
+}
+
+int sa_reserve(sa_handle *h, int max_batch)
+{
+    if (!h) return SA_EINVAL;
+    if (max_batch < 0) return fail(h, SA_ESHAPE, "sa_reserve: negative batch");
+    if (max_batch <= h->work_frames) return SA_OK;
+    SA_HIP(h, hipSetDevice(h->device));
+    SA_HIP(h, hipDeviceSynchronize());
+    if (h->d_work) SA_HIP(h, hipFree(h->d_work));
+    h->d_work = nullptr;
+    h->work_frames = 0;
+    SA_HIP(h, hipMalloc(&h->d_work, (size_t)max_batch * SA_NPTS * sizeof(int16_t)));
+    h->work_frames = max_batch;
+    return SA_OK;
+}
+
+int sa_set_filter_mode(sa_handle *h, uint8_t cmd)
+{
+    if (!h) return SA_EINVAL;
+    if (cmd != SA_FILTER_DEFAULT && cmd != SA_FILTER_CUSTOM && cmd != SA_FILTER_NONE && cmd != SA_FILTER_WIDE)
+        return fail(h, SA_EINVAL, "sa_set_filter_mode: not a filter-select byte (0x00, 0xA1, 0xB1, 0xA2)");
+    h->filter_mode = cmd;
+    return SA_OK;
+}
+
+int sa_get_filter_mode(const sa_handle *h, uint8_t *cmd)
+{
+    if (!h || !cmd) return SA_EINVAL;
+    *cmd = h->filter_mode;
+    return SA_OK;
+}
+
+int sa_load_coeffs_q7(sa_handle *h, const int8_t c[12])
+{
+    if (!h) return SA_EINVAL;
+    if (!c) return fail(h, SA_EINVAL, "sa_load_coeffs_q7: NULL coefficients");
+    std::memcpy(h->c12_custom, c, 12);
+    double sos[36];
+    sos_from_q7(h->c12_custom, sos);
+    return set_custom_plan(h, sos, 6);
+}
+
+int sa_get_coeffs_q7(const sa_handle *h, int8_t c[12])
+{
+    if (!h || !c) return SA_EINVAL;
+    std::memcpy(c, h->c12_custom, 12);
+    return SA_OK;
+}
+
+int sa_feed_command_bytes(sa_handle *h, const uint8_t *bytes, size_t n, int *n_frames_requested)
+{
+    if (!h) return SA_EINVAL;
+    if (!bytes && n) return fail(h, SA_EINVAL, "sa_feed_command_bytes: NULL bytes");
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t b = bytes[i];
+        if (h->rx_count >= 0) {                      // ACQUIRE: busy, byte is a coefficient
+            h->rx_buf[h->rx_count++] = (int8_t)b;
+            if (h->rx_count == 12) {
+                h->rx_count = -1;
+                const int rc = sa_load_coeffs_q7(h, h->rx_buf);
+                if (rc != SA_OK) return rc;
+            }
+            continue;
+        }
+        switch (b) {                                 // IDLE: command decode (command_control.vhd:53-62)
+            case SA_CMD_FILTER_UPDATE: h->rx_count = 0; break;
+            case SA_FILTER_DEFAULT:
+            case SA_FILTER_CUSTOM:
+            case SA_FILTER_NONE: h->filter_mode = b; break;
+            case SA_CMD_RESET: {                     // rst: mode B1 (:50), coefficients cleared (filter_iir12_cust.vhd:51-52)
+                h->filter_mode = SA_FILTER_NONE;
+                const int8_t z[12] = {0};
+                const int rc = sa_load_coeffs_q7(h, z);
+                if (rc != SA_OK) return rc;
+                break;
+            }
+            case SA_CMD_START:
+            case SA_CMD_UART_REQUEST:
+                if (n_frames_requested) ++*n_frames_requested;
+                break;
+            default: break;                          // 0xEF / 0xFE transport select and unknown bytes: no effect here
+        }
+    }
+    return SA_OK;
+}
+
+int sa_load_sos_f64(sa_handle *h, const double *sos, int n_sections)
+{
+    if (!h) return SA_EINVAL;
+    if (!sos) return fail(h, SA_EINVAL, "sa_load_sos: NULL sos");
+    if (n_sections < 0 || n_sections > SA_MAXSEC) return fail(h, SA_EINVAL, "sa_load_sos: 0..6 sections");
+    double norm[36];
+    for (int s = 0; s < n_sections; ++s) {
+        const double a0 = sos[6 * s + 3];
+        if (a0 == 0.0 || !std::isfinite(a0)) return fail(h, SA_EINVAL, "sa_load_sos: a0 must be finite and non-zero");
+        for (int i = 0; i < 6; ++i) norm[6 * s + i] = sos[6 * s + i] / a0;
+    }
+    return set_custom_plan(h, norm, n_sections);
+}
+
+int sa_load_sos_f32(sa_handle *h, const float *sos, int n_sections)
+{
+    if (!h) return SA_EINVAL;
+    if (!sos) return fail(h, SA_EINVAL, "sa_load_sos: NULL sos");
+    if (n_sections < 0 || n_sections > SA_MAXSEC) return fail(h, SA_EINVAL, "sa_load_sos: 0..6 sections");
+    double d[36];
+    for (int i = 0; i < 6 * n_sections; ++i) d[i] = (double)sos[i];
+    return sa_load_sos_f64(h, d, n_sections);
+}
+
+int sa_load_sos_q14(sa_handle *h, const int16_t *sos, int n_sections)
+{
+    if (!h) return SA_EINVAL;
+    if (!sos) return fail(h, SA_EINVAL, "sa_load_sos_q14: NULL sos");
+    if (n_sections < 0 || n_sections > SA_MAXSEC) return fail(h, SA_EINVAL, "sa_load_sos_q14: 0..6 sections");
+    std::memset(h->sos_q14, 0, sizeof h->sos_q14);
+    std::memcpy(h->sos_q14, sos, sizeof(int16_t) * 6 * n_sections);
+    h->nsec_q14 = n_sections;
+    return SA_OK;
+}
+
+int sa_set_window_q15(sa_handle *h, const int16_t *w)
+{
+    if (!h) return SA_EINVAL;
+    if (w) h->rom.assign(w, w + SA_NPTS); else default_rom(h->rom);
+    return upload(h, h->d_rom, h->rom.data(), sizeof(int16_t) * SA_NPTS);
+}
+
+int sa_get_window_q15(const sa_handle *h, int16_t *w)
+{
+    if (!h || !w) return SA_EINVAL;
+    std::memcpy(w, h->rom.data(), sizeof(int16_t) * SA_NPTS);
+    return SA_OK;
+}
+
+int sa_set_window_f32(sa_handle *h, const float *w)
+{
+    if (!h) return SA_EINVAL;
+    if (w) return set_window_f32_from(h, w);
+    std::vector<double> d;
+    default_window_f64(d);
+    std::vector<float> half(SA_NPTS);
+    for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * d[i]);
+    return upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+}
+
+int sa_set_window_mode_q15(sa_handle *h, int mode)
+{
+    if (!h) return SA_EINVAL;
+    if (mode != SA_WIN_RTL_SIGNED && mode != SA_WIN_HANN_U16) return fail(h, SA_EINVAL, "sa_set_window_mode_q15: bad mode");
+    h->win_mode_q15 = mode;
+    return SA_OK;
+}
+
+static int q15_params(sa_handle *h, SaQ15Params *p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->win_mode = h->win_mode_q15;
+    p->filter = h->filter_mode;
+    p->nsec_wide = h->nsec_q14;
+    if (h->filter_mode == SA_FILTER_DEFAULT) std::memcpy(p->c12, kDefaultQ7, 12);
+    else std::memcpy(p->c12, h->c12_custom, 12);
+    std::memcpy(p->sos_q14, h->sos_q14, sizeof p->sos_q14);
+    if (h->filter_mode == SA_FILTER_WIDE && h->nsec_q14 == 0) p->filter = SA_FILTER_NONE;   // no sections = wire
+    return SA_OK;
+}
+
+int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch, void *stream)
+{
+    if (!h) return SA_EINVAL;
+    if (batch < 0) return fail(h, SA_ESHAPE, "sa_filter_q15: negative batch");
+    if (batch == 0) return SA_OK;
+    if (!in || !out_time) return fail(h, SA_EINVAL, "sa_filter_q15: NULL tensor");
+    SA_HIP(h, hipSetDevice(h->device));
+    SaQ15Params p;
+    q15_params(h, &p);
+    const SaQ15Tables t = {h->d_rom, h->d_twq};
+    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, (hipStream_t)stream));
+    return SA_OK;
+}
+
+int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, void *stream)
+{
+    if (!h) return SA_EINVAL;
+    if (batch < 0) return fail(h, SA_ESHAPE, "sa_process_q15: negative batch");
+    if (batch == 0) return SA_OK;
+    if (!in || !out_iq) return fail(h, SA_EINVAL, "sa_process_q15: NULL tensor");
+    SA_HIP(h, hipSetDevice(h->device));
+    SaQ15Params p;
+    q15_params(h, &p);
+    const SaQ15Tables t = {h->d_rom, h->d_twq};
+    if (p.filter == SA_FILTER_NONE) {
+        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, (hipStream_t)stream));
+        return SA_OK;
+    }
+    if (batch > h->work_frames) {
+        const int rc = sa_reserve(h, batch);
+        if (rc != SA_OK) return rc;
+    }
+    SA_HIP(h, sa_launch_filter_q15(in, h->d_work, batch, p, t, (hipStream_t)stream));
+    SA_HIP(h, sa_launch_fft_q15(h->d_work, out_iq, batch, false, p, t, (hipStream_t)stream));
+    return SA_OK;
+}
+
+int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_kind, void *stream)
+{
+    if (!h) return SA_EINVAL;
+    if (batch < 0) return fail(h, SA_ESHAPE, "sa_process_f32: negative batch");
+    if (out_kind < SA_OUT_MAG_FULL || out_kind > SA_OUT_TIME) return fail(h, SA_EINVAL, "sa_process_f32: bad out_kind");
+    if (batch == 0) return SA_OK;
+    if (!in || !out) return fail(h, SA_EINVAL, "sa_process_f32: NULL tensor");
+    if (h->filter_mode == SA_FILTER_WIDE)
+        return fail(h, SA_ESTATE, "sa_process_f32: filter mode 0xA2 (Q2.14) belongs to the Q15 path; use 0xA1 with sa_load_sos_f32");
+    SA_HIP(h, hipSetDevice(h->device));
+    SaF32Tables t = {h->d_win_half, h->d_twA, h->d_twB, h->d_twP, nullptr};
+    bool iir = false;
+    if (h->filter_mode == SA_FILTER_DEFAULT) {
+        t.plan = h->d_plan_default;
+        iir = true;
+    } else if (h->filter_mode == SA_FILTER_CUSTOM) {
+        t.plan = h->d_plan_custom;
+        iir = h->plan_custom.nsec > 0;
+    }
+    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, iir, t, (hipStream_t)stream));
+    return SA_OK;
+}
+
+int sa_pack_frame(const int16_t *iq_host, uint8_t *frame_bytes)
+{
+    if (!iq_host || !frame_bytes) return SA_EINVAL;
+    for (int i = 0; i < SA_NPTS * 2; ++i) {          // explicit little-endian, independent of the host
+        const uint16_t v = (uint16_t)iq_host[i];
+        frame_bytes[2 * i] = (uint8_t)(v & 0xFF);
+        frame_bytes[2 * i + 1] = (uint8_t)(v >> 8);
+    }
+    return SA_OK;
+}
+
+int sa_debug_iir_plan_f32(const sa_handle *h, float *out, int cap)
+{
+    if (!h) return SA_EINVAL;
+    const SaIirPlan *p = (h->filter_mode == SA_FILTER_DEFAULT) ? &h->plan_default : &h->plan_custom;
+    const int need = (int)(sizeof(SaIirPlan) / sizeof(float));
+    if (out && cap > 0) std::memcpy(out, p, sizeof(float) * (size_t)(cap < need ? cap : need));
+    return need;
+}
+
+int sa_iir_plan_from_sos(const double *sos, int n_sections, float *out, int cap)
+{
+    if (!sos || n_sections < 0 || n_sections > SA_MAXSEC) return SA_EINVAL;
+    double norm[36];
+    for (int s = 0; s < n_sections; ++s) {
+        const double a0 = sos[6 * s + 3];
+        if (a0 == 0.0 || !std::isfinite(a0)) return SA_EINVAL;
+        for (int i = 0; i < 6; ++i) norm[6 * s + i] = sos[6 * s + i] / a0;
+    }
+    SaIirPlan p;
+    build_plan(norm, n_sections, &p);
+    const int need = (int)(sizeof(SaIirPlan) / sizeof(float));
+    if (out && cap > 0) std::memcpy(out, &p, sizeof(float) * (size_t)(cap < need ? cap : need));
+    return need;
+}
+
+}  // extern "C"

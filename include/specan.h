@@ -1,0 +1,154 @@
+/*
+ * specan.h -- C ABI of the MI355X spectrum-analyser signal path (libspecan_hip.so).
+ *
+ * Drop-in boundary for the hot path of mfkiwl/fpga-real-time-fft-analyzer:
+ *     hann_window  ->  filter_iir12 | filter_iir12_cust  ->  xfft_0 (16384-pt)  ->  frame bytes
+ * The reference exposes no FFI; its boundary is the byte contract between the FPGA and
+ * scripts/fft_analyzer_gui.py.  Every entry point below cites the reference interface it
+ * replaces (paths relative to the reference root; new/ = SDR_v2.srcs/sources_1/new,
+ * imp/ = SDR_v2.srcs/sources_1/imports/new, gui.py = scripts/fft_analyzer_gui.py).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures: device pointers are `void*`-compatible raw
+ *     pointers (tensor.data_ptr()), the stream is a `void*` holding a hipStream_t
+ *     (torch.cuda.current_stream().cuda_stream); NULL = the null stream.
+ *   - every call returns 0 (SA_OK) or a negative SA_E* code; sa_last_error() gives the text.
+ *     No exception or abort crosses the ABI.  There is NO CPU fallback: without a usable GPU
+ *     sa_create() fails with SA_EHIP.
+ *   - the library never allocates, frees or retains caller tensors.  It owns the opaque handle,
+ *     its device-side tables and (for the Q15 IIR modes) a workspace sized by sa_reserve().
+ *   - a handle is not thread-safe; use one handle per (GPU, stream).  process calls are
+ *     asynchronous on the given stream; mode / coefficient / window changes are stream-ordered:
+ *     they apply to every process call issued after them.
+ *   - frame length is fixed: SA_N = 16384 samples (gui.py:43-44, imp/dsp_system_top.vhd:440,
+ *     ip/xfft_0/xfft_0.xci:12).
+ */
+#ifndef SPECAN_H_
+#define SPECAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_N 16384
+#define SA_FRAME_BYTES 65536          /* gui.py:42  FRAME_SIZE_BYTES */
+#define SA_ABI_VERSION 1
+
+/* error codes */
+#define SA_OK       0
+#define SA_EINVAL  -1   /* bad argument (NULL pointer, bad enum, bad section count) */
+#define SA_ESHAPE  -2   /* bad batch / shape */
+#define SA_EHIP    -3   /* HIP runtime error; text in sa_last_error() */
+#define SA_ESTATE  -4   /* call not valid in the current state (e.g. mode needs coefficients) */
+#define SA_ENOMEM  -5
+
+/* filter-select command bytes: gui.py:35-37, decoded in new/command_control.vhd:53-58.
+ * Power-on / reset value is SA_FILTER_NONE (new/command_control.vhd:31). */
+#define SA_FILTER_DEFAULT 0x00   /* fixed ALPHA/BETA cascade, imp/filter_iir12.vhd + imp/filter_pkg.vhd:54-68 */
+#define SA_FILTER_CUSTOM  0xA1   /* uploaded coefficients, new/filter_iir12_cust.vhd */
+#define SA_FILTER_NONE    0xB1   /* window -> FFT directly */
+#define SA_FILTER_WIDE    0xA2   /* build extension (not a reference byte): 6 independent Q2.14 sections */
+
+/* other command bytes understood by sa_feed_command_bytes(): gui.py:28-33 */
+#define SA_CMD_START          0x55
+#define SA_CMD_UART_REQUEST   0xA5
+#define SA_CMD_RESET          0xFF
+#define SA_CMD_ETHERNET_MODE  0xEF
+#define SA_CMD_UART_MODE      0xFE
+#define SA_CMD_FILTER_UPDATE  0xF1   /* followed by 12 coefficient bytes, new/rx_filter_coeff.vhd:45-56 */
+
+/* Q15 window modes */
+#define SA_WIN_RTL_SIGNED 0   /* new/hann8192.vhd:36-39: ROM word used as signed Q15 (FPGA-exact) */
+#define SA_WIN_HANN_U16   1   /* ROM + 32768 as unsigned Q16 Hann (the evident intent) */
+
+/* float output layouts for sa_process_f32() */
+#define SA_OUT_MAG_FULL   0   /* float  [B,16384]   |X[k]|, all N bins (upper half mirrored; gui.py:294-305 plots all N) */
+#define SA_OUT_MAG_HALF   1   /* float  [B,8193]    |X[k]|, k = 0..N/2 */
+#define SA_OUT_SPEC_HALF  2   /* float2 [B,8193]    X[k] = (re,im), k = 0..N/2 (numpy.fft.rfft layout) */
+#define SA_OUT_TIME       3   /* float  [B,16384]   FFT input: window (+ IIR) output time series */
+
+typedef struct sa_handle sa_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* Stands for "power on the board": state = filter NONE, zero custom coefficients
+ * (new/filter_iir12_cust.vhd:51-52), default Hann ROM (new/hann.vhd, scripts/hann_coeff.py:3-5). */
+int sa_create(int device, sa_handle **out);
+int sa_destroy(sa_handle *h);
+int sa_abi_version(void);
+const char *sa_last_error(const sa_handle *h);   /* h may be NULL: last sa_create() failure */
+
+/* Pre-size the internal workspace for batches up to max_batch frames (Q15 IIR modes need
+ * B*32 KiB).  Optional: process calls grow it on demand (not capturable into a hipGraph then). */
+int sa_reserve(sa_handle *h, int max_batch);
+
+/* ---- control plane of the path (what the UART bytes do) -------------------------------- */
+/* new/command_control.vhd:53-58: accepts SA_FILTER_DEFAULT / CUSTOM / NONE (and SA_FILTER_WIDE). */
+int sa_set_filter_mode(sa_handle *h, uint8_t cmd);
+int sa_get_filter_mode(const sa_handle *h, uint8_t *cmd);
+
+/* 12 int8 coefficients in wire order [b0,b1,b2,a0,a1,a2] x 2 (gui.py:598-605), stored into
+ * COEFF_IIR_CF(0..11) (new/filter_iir12_cust.vhd:54, ports :83-94).  Semantics per the RTL:
+ * stage taps B2*x[n]+B1*x[n-1]+B0*x[n-2]-A0*y[n-2]-A1*y[n-1], each product >>7, 16-bit wrap;
+ * set 0 drives stages 1,3,5 and set 1 stages 2,4,6; A2 is unused (new/filter_iir_cust.vhd:96-117).
+ * The float path (sa_process_f32) uses the same taps as real numbers c/128. */
+int sa_load_coeffs_q7(sa_handle *h, const int8_t c[12]);
+int sa_get_coeffs_q7(const sa_handle *h, int8_t c[12]);
+
+/* Byte-stream front door: the UART RX path (imp/uart_rx.vhd -> new/rx_filter_coeff.vhd:41-66
+ * + new/command_control.vhd:51-62).  0xF1 starts a 12-byte coefficient upload during which no
+ * byte is interpreted as a command; 0x00/0xA1/0xB1 select the filter; 0xFF resets (filter NONE,
+ * coefficients cleared); 0x55/0xA5/0xEF/0xFE are accepted and counted but have no effect on the
+ * signal path.  Unknown bytes are ignored, like the RTL.  *n_frames_requested (optional) is
+ * incremented once per 0xA5 / 0x55 seen, so a transport shim knows to emit frames. */
+int sa_feed_command_bytes(sa_handle *h, const uint8_t *bytes, size_t n, int *n_frames_requested);
+
+/* North-star wide formats (not in the reference): up to 6 independent sections, scipy row order
+ * [b0,b1,b2,a0,a1,a2], normalised by a0 on load.  f32/f64 feed sa_process_f32 in CUSTOM mode;
+ * q14 (int16 Q2.14, a0 ignored) feeds sa_process_q15 in WIDE mode. */
+int sa_load_sos_f32(sa_handle *h, const float *sos, int n_sections);
+int sa_load_sos_f64(sa_handle *h, const double *sos, int n_sections);
+int sa_load_sos_q14(sa_handle *h, const int16_t *sos, int n_sections);
+
+/* Window tables (host pointers, copied).  NULL restores the default generated with the formula of
+ * scripts/hann_coeff.py:3-5 (the Q15 table includes the int16 wrap of entries 8178..8205). */
+int sa_set_window_q15(sa_handle *h, const int16_t *w /* [16384] or NULL */);
+int sa_set_window_f32(sa_handle *h, const float *w /* [16384] or NULL */);
+int sa_set_window_mode_q15(sa_handle *h, int mode /* SA_WIN_* */);
+int sa_get_window_q15(const sa_handle *h, int16_t *w /* [16384] */);
+
+/* ---- data plane ----------------------------------------------------------------------- */
+/* Q15 path, bit-exact integer pipeline: in [B,16384] int16 device (samples as the XADC delivers
+ * them, imp/dsp_system_top.vhd:435) -> out_iq [B,16384,2] int16 device = the 65536-byte frames of
+ * imp/sequ2.vhd:153 / gui.py:250-260 (re lo,hi, im lo,hi).  FFT = SA-FXFFT-1:
+ * stands where ip/xfft_0 stands; 1/N scaling, truncation. */
+int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, void *stream);
+
+/* Window (+ integer IIR) only: the FFT input stream, [B,16384] int16 (fft_in16 of
+ * new/command_control.vhd:90-123). */
+int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch, void *stream);
+
+/* float path: in [B,16384] float32 device -> out per out_kind (SA_OUT_*), device.
+ * Equals |rfft(sosfilt(sos, x*hann))| within 1e-5 (max-norm relative, per frame). */
+int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_kind, void *stream);
+
+/* Host helper: view of one frame as the byte stream sequ2 emits.  On little-endian hosts the
+ * Q15 output already is that stream; this copies 65536 bytes and is provided for symmetry with
+ * gui.py:250-260 (decode side). */
+int sa_pack_frame(const int16_t *iq_host /* [16384,2] */, uint8_t *frame_bytes /* [65536] */);
+
+/* Introspection for tests / tuning: the float IIR plan the kernels consume (chunked-scan form of
+ * the cascade: per section 5 taps, predictor taps, state-transition powers).  Writes at most `cap`
+ * floats, returns the count needed (or a negative error). */
+int sa_debug_iir_plan_f32(const sa_handle *h, float *out, int cap);
+
+/* Same plan computed on the host from an SOS (scipy row order, a0-normalised here), without a
+ * handle or a GPU: pure host logic, used by the CPU tests to check the chunked-scan algebra. */
+int sa_iir_plan_from_sos(const double *sos, int n_sections, float *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECAN_H_ */

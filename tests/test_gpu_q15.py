@@ -1,0 +1,169 @@
+"""GPU: Q15 integer path, bit-exact against the integer model (oracle/specan_oracle.c) and the
+golden digests, through the C ABI."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import N, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture()
+def ch(chain_cls):
+    c = chain_cls(0)
+    yield c
+    c.close()
+
+
+def _dev(torch_mod, a):
+    return torch_mod.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_power_on_state(ch, oracle):
+    assert ch.filter_mode == 0xB1                                      # new/command_control.vhd:31
+    assert not ch.coeffs_q7().any()                                    # new/filter_iir12_cust.vhd:51-52
+    assert np.array_equal(ch.window_q15(), load_golden("g1_hann_rom.npz")["rom"])
+
+
+def test_golden_digests_all_modes(ch, torch_mod):
+    g = load_golden("g4_q15_frames.npz")
+    x = _dev(torch_mod, g["x"])
+    for name, cmd, c12 in (("bypass", 0xB1, None), ("default", 0x00, None), ("gui", 0xA1, g["c_gui"])):
+        if c12 is not None:
+            ch.load_coeffs_q7(c12)
+        ch.set_filter_mode(cmd)
+        t = ch.filter_q15(x).cpu().numpy()
+        iq = ch.process_q15(x).cpu().numpy()
+        assert np.array_equal(t[2], g[f"time_{name}_f2"])
+        assert [sha(t[i]) for i in range(4)] == list(g[f"time_{name}_sha"])
+        assert [sha(iq[i]) for i in range(4)] == list(g[f"iq_{name}_sha"])
+    # wide Q2.14 mode with the unsigned-Hann window
+    ch.load_sos_q14(g["sos_q14"])
+    ch.set_window_mode_q15(1)
+    ch.set_filter_mode(0xA2)
+    t = ch.filter_q15(x).cpu().numpy()
+    iq = ch.process_q15(x).cpu().numpy()
+    assert np.array_equal(t[2], g["time_wide_f2"])
+    assert [sha(iq[i]) for i in range(4)] == list(g["iq_wide_sha"])
+
+
+@pytest.mark.parametrize("B,cmd", [(1, 0xB1), (7, 0x00), (9, 0xA1), (33, 0xB1), (64, 0x00)])
+def test_bit_exact_vs_integer_model(ch, torch_mod, oracle, B, cmd):
+    rng = np.random.default_rng(B * 7 + cmd)
+    x = rng.integers(-2048, 2048, size=(B, N)).astype(np.int16)
+    x[-1] = rng.integers(-32768, 32768, size=N)                      # one full-scale frame
+    c12 = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
+    ch.load_coeffs_q7(c12)
+    ch.set_filter_mode(cmd)
+    ref_iq, ref_t = oracle.chain_q15(x, None, 0, cmd, c12, None, want_time=True)
+    xd = _dev(torch_mod, x)
+    assert np.array_equal(ch.filter_q15(xd).cpu().numpy(), ref_t)
+    assert np.array_equal(ch.process_q15(xd).cpu().numpy(), ref_iq)
+
+
+def test_extreme_inputs(ch, torch_mod, oracle):
+    x = np.zeros((4, N), np.int16)
+    x[0] = 32767
+    x[1] = -32768
+    x[2, ::2] = 32767
+    x[2, 1::2] = -32768
+    x[3, 0] = -32768
+    for cmd in (0xB1, 0x00):
+        ch.set_filter_mode(cmd)
+        ref = oracle.chain_q15(x, None, 0, cmd, None, None)
+        assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), ref)
+    e = torch_mod.empty((0, N), dtype=torch_mod.int16, device="cuda")
+    assert ch.process_q15(e).shape == (0, N, 2)
+
+
+def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
+    rng = np.random.default_rng(99)
+    x = rng.integers(-2048, 2048, size=(3, N)).astype(np.int16)
+    rom = rng.integers(-32768, 32768, size=N).astype(np.int16)
+    ch.set_window_q15(rom)
+    for wm in (0, 1):
+        ch.set_window_mode_q15(wm)
+        ref = oracle.chain_q15(x, rom, wm, 0xB1, None, None)
+        assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), ref)
+    ch.set_window_q15(None)
+    ch.set_window_mode_q15(0)
+    assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), oracle.chain_q15(x))
+
+
+def test_command_byte_stream(ch, torch_mod, oracle):
+    """UART bytes drive the path exactly like the RTL front door (rx_filter_coeff + command_control)."""
+    from fpga_real_time_fft_analyzer_amd import designer
+    q = designer.quantize_coefficients(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0))
+    wire = ch.send_filter_coefficients(designer.two_sections_for_fpga(q))
+    assert wire == designer.coefficient_upload_bytes(q)
+    assert ch.coeffs_q7().tolist() == [0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40]
+    assert ch.filter_mode == 0xB1                                     # upload does not select the filter
+    assert ch.feed_command_bytes(bytes([0xA1])) == 0 and ch.filter_mode == 0xA1
+    # coefficient bytes that look like commands are not decoded while busy
+    ch.feed_command_bytes(bytes([0xF1] + [0x00, 0xB1, 0xFF, 0x55, 0xA5, 0xF1, 1, 2, 3, 4, 5, 6]))
+    assert ch.filter_mode == 0xA1
+    assert ch.coeffs_q7().tolist() == [0, -79, -1, 0x55, -91, -15, 1, 2, 3, 4, 5, 6]
+    # split delivery, unknown bytes ignored, frame requests counted
+    assert ch.feed_command_bytes(bytes([0x42, 0x55, 0xA5, 0xEF, 0xFE, 0xF1, 9, 9])) == 2
+    ch.feed_command_bytes(bytes([9] * 10))
+    assert ch.coeffs_q7().tolist() == [9] * 12
+    ch.feed_command_bytes(bytes([0x00]))
+    assert ch.filter_mode == 0x00
+    ch.feed_command_bytes(bytes([0xFF]))                               # reset
+    assert ch.filter_mode == 0xB1 and not ch.coeffs_q7().any()
+    # and the data path follows: custom mode with the GUI default upload
+    ch.feed_command_bytes(wire + bytes([0xA1]))
+    x = np.random.default_rng(5).integers(-2048, 2048, size=(2, N)).astype(np.int16)
+    ref = oracle.chain_q15(x, None, 0, 0xA1, ch.coeffs_q7(), None)
+    assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), ref)
+
+
+def test_frames_feed_the_reference_decoder_contract(ch, torch_mod):
+    from fpga_real_time_fft_analyzer_amd import frames
+    g6 = load_golden("g6_frame.npz")
+    g4 = load_golden("g4_q15_frames.npz")
+    ch.set_filter_mode(0x00)
+    iq = ch.process_q15(_dev(torch_mod, g4["x"][2:3]))
+    fb = ch.frames_bytes(iq)
+    assert len(fb) == 1 and fb[0] == g6["frame"].tobytes()
+    assert np.array_equal(frames.decode_mag_16iq_le(fb[0]), g6["mag"])
+
+
+def test_fxfft_close_to_float_fft_on_gpu(ch, torch_mod):
+    rng = np.random.default_rng(1)
+    x = rng.integers(-2048, 2048, size=(8, N)).astype(np.int16)
+    rom = np.full(N, 32767, np.int16)                                  # ~unity window
+    ch.set_window_q15(rom)
+    iq = ch.process_q15(_dev(torch_mod, x)).cpu().numpy().astype(np.float64)
+    ref = np.fft.fft(x.astype(np.float64), axis=-1) / N
+    assert np.abs(iq[..., 0] + 1j * iq[..., 1] - ref).max() <= 7.0
+
+
+def test_full_size_batch(ch, torch_mod, oracle):
+    """BASELINE config 4 size: B=4096, bit-exact on sampled frames + digest-of-batch stability."""
+    torch = torch_mod
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    B = 4096
+    x = torch.randint(-2048, 2048, (B, N), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
+    ch.reserve(B)
+    ch.set_filter_mode(0x00)
+    iq = ch.process_q15(x)
+    idx = [0, 1, 511, 2047, 4095]
+    ref = oracle.chain_q15(x[idx].cpu().numpy(), None, 0, 0x00, None, None)
+    assert np.array_equal(iq[idx].cpu().numpy(), ref)
+    perm = torch.randperm(B, generator=gen, device="cuda")
+    iq2 = ch.process_q15(x[perm].contiguous())
+    assert torch.equal(iq2, iq[perm])

@@ -1,0 +1,174 @@
+"""CPU: host-side logic -- designer/quantiser mirror, frame helpers, IIR plan algebra."""
+import numpy as np
+import pytest
+
+from conftest import N, load_golden, rel_maxnorm
+from fpga_real_time_fft_analyzer_amd import designer, frames
+
+
+# ---- IIR-4: designer + quantiser against the reference's outputs (G5)
+@pytest.mark.parametrize("kind", ["butter", "cheby1", "cheby2", "ellip", "bessel"])
+def test_designer_and_quantiser_match_reference(kind):
+    g = load_golden("g5_quantiser.npz")
+    sos = designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0, kind=kind, ripple=1.0, attenuation=40)
+    assert np.allclose(sos, g[f"sos_{kind}"], rtol=1e-12, atol=0)
+    q = np.array(designer.quantize_coefficients(sos), dtype=np.int8)
+    assert np.array_equal(q, g[f"q_{kind}"])
+
+
+@pytest.mark.parametrize("ft", ["highpass", "bandpass", "bandstop"])
+def test_designer_filter_types(ft):
+    g = load_golden("g5_quantiser.npz")
+    sos = designer.design_iir_filter(ft, 4, 10.0, 20.0, 100.0, kind="butter")
+    assert np.allclose(sos, g[f"sos_butter_{ft}"], rtol=1e-12)
+    assert np.array_equal(np.array(designer.quantize_coefficients(sos), np.int8), g[f"q_butter_{ft}"])
+
+
+def test_designer_defaults_and_errors():
+    g = load_golden("g5_quantiser.npz")
+    q = designer.quantize_coefficients(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0))
+    assert np.array(q).tolist() == [[0, 1, 0, 64, -67, 19], [64, 127, 64, 64, -85, 40]]     # SURVEY IIR-4
+    q12 = np.array(designer.quantize_coefficients(designer.design_iir_filter("lowpass", 12, 10.0, None, 100.0)))
+    assert np.array_equal(q12, g["q_butter12"]) and q12[0].tolist() == [0, 0, 0, 64, -65, 17]
+    with pytest.raises(ValueError):
+        designer.design_iir_filter("lowpass", 4, 10.0, kind="fir")
+    # band types default cutoff2 = 2*cutoff (gui.py:134-135)
+    a = designer.design_iir_filter("bandpass", 2, 10.0, None, 100.0)
+    b = designer.design_iir_filter("bandpass", 2, 10.0, 20.0, 100.0)
+    assert np.array_equal(a, b)
+
+
+def test_upload_bytes_and_padding():
+    q = designer.quantize_coefficients(designer.design_iir_filter("lowpass", 2, 10.0, 20.0, 100.0))
+    secs = designer.two_sections_for_fpga(q)
+    assert len(secs) == 2 and secs[1] == [64, 0, 0, 64, 0, 0]             # gui.py:1190
+    q12 = designer.quantize_coefficients(designer.design_iir_filter("lowpass", 12, 10.0, 20.0, 100.0))
+    assert len(designer.two_sections_for_fpga(q12)) == 2                     # gui.py:1186-1187 truncation
+    b = designer.coefficient_upload_bytes([[0, 1, 0, 64, -67, 19], [64, 127, 64, 64, -85, 40]])
+    assert b == bytes([0xF1, 0, 1, 0, 64, 0xBD, 19, 64, 127, 64, 64, 0xAB, 40])
+    assert designer.int8_to_byte(-1) == 255 and designer.int8_to_byte(127) == 127
+
+
+def test_q14_quantiser(oracle):
+    sos = load_golden("g2_config1.npz")["sos"]
+    assert np.array_equal(designer.quantize_sos_q14(sos), oracle.quantize_sos_q14(sos))
+    assert np.array_equal(designer.quantize_sos_q14(sos), load_golden("g4_q15_frames.npz")["sos_q14"])
+
+
+# ---- OUT-1: frame helpers against the reference decoder's output (G6)
+def test_frame_helpers():
+    g = load_golden("g6_frame.npz")
+    frame = g["frame"].tobytes()
+    assert np.array_equal(frames.decode_mag_16iq_le(frame), g["mag"])
+    re, im = frames.decode_iq_components(frame)
+    assert np.array_equal(re, g["re"]) and np.array_equal(im, g["im"])
+    with pytest.raises(ValueError):
+        frames.decode_mag_16iq_le(frame[:-1])
+    assert frames.frequency_axis_khz()[1] == pytest.approx(1e6 / 16384 / 1e3)
+
+
+def test_udp_packetiser_roundtrip():
+    g = load_golden("g6_frame.npz")
+    frame = g["frame"].tobytes()
+    pk = frames.frame_to_udp_payloads(frame)
+    assert len(pk) == 64 and all(len(p) == 1025 for p in pk) and [p[0] for p in pk] == list(range(64))
+    asm = frames.FrameAssembler()
+    order = list(range(64))
+    np.random.default_rng(3).shuffle(order)
+    got = None
+    for i in order:
+        assert got is None
+        got = asm.add(pk[i], 0)
+    assert got == frame and asm.frame_id == 1
+    assert asm.add(b"\x40" + bytes(1024), 0) is None          # index out of range ignored
+    assert asm.add(bytes(10), 0) is None                      # wrong length ignored
+    asm.add(pk[0], 0)
+    asm.add(pk[1], 5000)                                      # evicts the stale slot 0
+    assert asm.get_completion_status() == (1, 64)
+
+
+def test_pack_frame_is_little_endian(hip_lib_built):
+    from fpga_real_time_fft_analyzer_amd.chain import pack_frame
+    g = load_golden("g6_frame.npz")
+    iq = np.frombuffer(g["frame"].tobytes(), "<i2").reshape(N, 2)
+    assert pack_frame(iq) == g["frame"].tobytes()
+
+
+# ---- IIR plan algebra: emulate the kernel's predict / scan / recurse in float32 on the CPU
+def _parse_plan(plan):
+    nsec = int(plan[:1].view(np.int32)[0])
+    off, secs = 4, []
+    for _ in range(6):
+        c = plan[off:off + 8]; off += 8
+        plev = plan[off:off + 24].reshape(6, 4); off += 24
+        p64 = plan[off:off + 4]; off += 4
+        m = plan[off:off + 128].reshape(2, 64); off += 128
+        ppow = plan[off:off + 256].reshape(64, 4); off += 256
+        secs.append((c, plev, p64, m, ppow))
+    assert off == plan.size
+    return nsec, secs
+
+
+def emulate_chunked_iir(plan, x):
+    """float32 emulation with the kernel's exact structure: per section predict -> Kogge-Stone scan
+    inside each group of 64 chunks -> carry over 4 groups -> DF2T recursion."""
+    f = np.float32
+    nsec, secs = _parse_plan(plan)
+    v = x.astype(f).reshape(256, 64).copy()
+    for s in range(nsec):
+        c, plev, p64, m, ppow = secs[s]
+        z = np.zeros((256, 2), f)
+        for j in range(64):
+            z[:, 0] += m[0, j] * v[:, j]
+            z[:, 1] += m[1, j] * v[:, j]
+        z = z.reshape(4, 64, 2)
+        for lev in range(6):
+            d = 1 << lev
+            p = plev[lev]
+            u = np.zeros_like(z)
+            u[:, d:, :] = z[:, :-d, :]
+            add0 = p[0] * u[..., 0] + p[1] * u[..., 1]
+            add1 = p[2] * u[..., 0] + p[3] * u[..., 1]
+            z = np.stack([z[..., 0] + add0, z[..., 1] + add1], axis=-1).astype(f)
+        tot = z[:, 63, :]
+        carry = np.zeros((4, 2), f)
+        for w in range(1, 4):
+            pc = carry[w - 1]
+            carry[w] = [p64[0] * pc[0] + p64[1] * pc[1] + tot[w - 1, 0], p64[2] * pc[0] + p64[3] * pc[1] + tot[w - 1, 1]]
+        e = np.zeros_like(z)
+        e[:, 1:, :] = z[:, :-1, :]
+        s1 = (e[..., 0] + ppow[None, :, 0] * carry[:, None, 0] + ppow[None, :, 1] * carry[:, None, 1]).astype(f).reshape(256)
+        s2 = (e[..., 1] + ppow[None, :, 2] * carry[:, None, 0] + ppow[None, :, 3] * carry[:, None, 1]).astype(f).reshape(256)
+        b0, b1, b2, a1, a2 = c[:5]
+        for j in range(64):
+            xx = v[:, j]
+            y = (b0 * xx + s1).astype(f)
+            s1 = (b1 * xx + s2 - a1 * y).astype(f)
+            s2 = (b2 * xx - a2 * y).astype(f)
+            v[:, j] = y
+    return v.reshape(-1)
+
+
+def test_iir_plan_reproduces_sosfilt(hip_lib_built, oracle):
+    from scipy.signal import sosfilt
+    from fpga_real_time_fft_analyzer_amd.chain import iir_plan_from_sos
+    g = load_golden("g3_fp32_frames.npz")
+    sos = g["sos"]
+    plan = iir_plan_from_sos(sos)
+    assert plan.size == 4 + 6 * (8 + 24 + 4 + 128 + 256)
+    hann = oracle.hann_f64()
+    for i in range(2):
+        xw = (g["x"][i].astype(np.float64) * hann).astype(np.float32)
+        ref = sosfilt(sos, xw.astype(np.float64))
+        y = emulate_chunked_iir(plan, xw)
+        assert rel_maxnorm(y[None, :], ref[None, :]) <= 1e-5
+
+
+def test_iir_plan_rejects_bad_sos(hip_lib_built):
+    from fpga_real_time_fft_analyzer_amd.abi import SpecanError
+    from fpga_real_time_fft_analyzer_amd.chain import iir_plan_from_sos
+    with pytest.raises(SpecanError):
+        iir_plan_from_sos(np.zeros((7, 6)))
+    with pytest.raises(SpecanError):
+        iir_plan_from_sos(np.array([[1, 0, 0, 0, 0, 0.0]]))     # a0 = 0
+    assert int(iir_plan_from_sos(np.zeros((0, 6)))[:1].view(np.int32)[0]) == 0
