@@ -3,299 +3,490 @@
 // replacing new/hann8192.vhd -> new/filter_iir12_cust.vhd -> ip/xfft_0 of the reference with one
 // pass over HBM (read 64 KiB, write 64 KiB per frame).  One 256-thread workgroup per frame.
 //
-// Layout of the computation (DESIGN.md sections 3-5):
-//   * thread t owns samples [64t, 64t+64) for the IIR (the recursion is serial in time), obtained
-//     through a coalesced global read + XOR-swizzled LDS transpose;
-//   * the IIR is evaluated per section as  predict (dot product giving each chunk's end state from
-//     zero state)  ->  scan over the 256 chunks (2x2 transition powers; wave shuffle + one LDS hop)
-//     ->  the exact DF2T recursion started from the scanned state;
+// Shape of the computation (DESIGN.md sections 3-5):
+//   * LDS holds HALF a frame at a time (35 KiB per workgroup) so that four workgroups share a CU
+//     (16 waves): every exchange is done in two index-split rounds.  The kernel is latency bound
+//     at lower occupancy (profiles/r1_b_phase_stamps.txt).
+//   * thread t owns samples [64t, 64t+64) for the IIR as two chunks of 32 held as float pairs
+//     (chunk A in .x, chunk B in .y) so the serial recursion runs on packed-fp32 instructions.
+//   * per section: the end state of every chunk from zero state is a dot product ("predict", fused
+//     into the previous section's recursion loop); an affine scan over the 512 chunks of the frame
+//     (in-row DPP shifts, one LDS hop for the 16 row totals) turns those into true start states;
+//     then the exact DF2T recursion of scipy.signal.sosfilt runs from them.
 //   * the real FFT is an 8192-point complex FFT of z[m] = x[2m] + i x[2m+1] factored 32 x 16 x 16,
-//     each factor done in registers (fft_regs.hpp), with padded LDS exchanges between factors,
-//     followed by the split step X[k] = Xe[k] + W_N^k Xo[k];
-//   * magnitudes of all 16384 bins are written (upper half mirrored), dword-per-lane coalesced.
+//     each factor in registers (fft_regs.hpp), then the split step X[k] = Xe[k] + W_N^k Xo[k].
+//   * all 16384 magnitudes are written (upper half mirrored), one dword per lane, coalesced.
 // The factor 1/2 of the split step is folded into the window table (exact in binary fp).
 #include "sa_common.hpp"
 #include "fft_regs.hpp"
 #include "../../include/specan.h"
 
 using safft::cf;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kLdsComplex = 32 * 272;                 // largest exchange layout (8704 complex)
-constexpr int kLdsBytes = kLdsComplex * 8 + 256;      // + scan scratch (6 sections x 4 waves x 2 floats)
+constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange image (4352 complex)
+constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 sections x 16 rows x float2
+constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
+constexpr int kMtabOff = kSideOff + 16;               // two complex side slots, then the predictor taps
+constexpr int kLdsBytes = kMtabOff + SA_MAXSEC * SA_CHUNK * 2 * 4;
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 
+// Phase stamps: diagnostic build only (make stamps -> libspecan_hip_stamps.so, tools/phase_stamps.py).
+// In the product build SA_STAMP expands to nothing.
+#ifdef SA_STAMPS
+__device__ unsigned long long *g_sa_stamps = nullptr;
+#define SA_STAMP(i)                                                                        \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (threadIdx.x == 0) {                                                            \
+            unsigned long long c_;                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");     \
+            g_sa_stamps[(size_t)blockIdx.x * 16 + (i)] = c_;                               \
+        }                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define SA_STAMP(i) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
-// Stage-in for the IIR: coalesced 16-byte loads, window multiply, swizzled LDS transpose so that
-// thread t ends with its 64 consecutive samples in v[].
-// LDS image: row r = chunk (256 B), 16-byte column c stored at column c ^ (r & 15).
-__device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, const float *__restrict__ win,
-                                                float4 *lds4, int t, float (&v)[64])
+// DPP helpers: value of the lane `n` to the left inside the 16-lane row, 0 when there is none.
+template <int N>
+__device__ __forceinline__ float row_shr(float v)
 {
-    const float4 *x4 = reinterpret_cast<const float4 *>(xin);
-    const float4 *w4 = reinterpret_cast<const float4 *>(win);
-    float4 xv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int u = i * 256 + t;
-        const float4 a = x4[u];
-        const float4 w = w4[u];
-        xv[i] = make_float4(a.x * w.x, a.y * w.y, a.z * w.z, a.w * w.w);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = i * 16 + (t >> 4);
-        const int pc = (t & 15) ^ (r & 15);
-        lds4[r * 16 + pc] = xv[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float4 q = lds4[t * 16 + (j ^ (t & 15))];
-        v[4 * j + 0] = q.x;
-        v[4 * j + 1] = q.y;
-        v[4 * j + 2] = q.z;
-        v[4 * j + 3] = q.w;
-    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float lane_get(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+// z <- z + P * shifted(z): one Kogge-Stone level of the affine scan inside a row
+template <int N>
+__device__ __forceinline__ void scan_level(float &z1, float &z2, const float (&p)[4])
+{
+    const float u1 = row_shr<N>(z1), u2 = row_shr<N>(z2);
+    z1 = __builtin_fmaf(p[0], u1, __builtin_fmaf(p[1], u2, z1));
+    z2 = __builtin_fmaf(p[2], u1, __builtin_fmaf(p[3], u2, z2));
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cascade over the thread's chunk, all sections, in place.  scr: LDS scratch [6][4] float2.
-__device__ __forceinline__ void iir_cascade(float (&v)[64], const SaIirPlan *__restrict__ plan, float2 *scr,
-                                            int t)
+// Stage-in for the IIR, two rounds.  Round h brings chunk h (32 samples = 128 B) of every thread:
+// the samples go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write), 1 KiB = 8 rows
+// of 128 B per wave instruction.  The LDS image is linear per instruction, so the XOR swizzle (16-byte
+// column c of row r stored at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 at a 128-byte row pitch)
+// is applied to the per-lane SOURCE address.  Each thread then reads its own 32 consecutive samples
+// and multiplies by the window, which the host stored transposed (wint[g][t] = window[64t + 4g .. +3])
+// so that its loads are coalesced in this layout.
+// Thread t ends with d[j] = (x[64t + j], x[64t + 32 + j]) * window.
+__device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, const float4 *__restrict__ wint,
+                                                unsigned char *smem, int t, v2f (&d)[32])
 {
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int nsec = plan->nsec;
-    for (int s = 0; s < nsec; ++s) {
-        const SaIirSecPlan &sp = plan->sec[s];
-        // predict: end state of this chunk from zero initial state
-        float z1a = 0.f, z1b = 0.f, z2a = 0.f, z2b = 0.f;
+    const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
+    const int lane = t & 63, wave = t >> 6;
+    // per-lane byte offset of its 16-byte source column inside the slab of 8 chunk rows (256 B apart)
+    const int rl = lane >> 3;                                  // row inside the slab
 #pragma unroll
-        for (int j = 0; j < 64; j += 2) {
-            z1a = __builtin_fmaf(sp.m[0][j], v[j], z1a);
-            z2a = __builtin_fmaf(sp.m[1][j], v[j], z2a);
-            z1b = __builtin_fmaf(sp.m[0][j + 1], v[j + 1], z1b);
-            z2b = __builtin_fmaf(sp.m[1][j + 1], v[j + 1], z2b);
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1) __syncthreads();          // round-0 readers are done with the image
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = wave * 8 + i;                        // slab: rows 8n .. 8n+7
+            const int r = 8 * n + rl;
+            const int lc = (lane & 7) ^ ((r >> 1) & 7);
+            const float *src = xin + r * 64 + h * 32 + lc * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
         }
-        float z1 = z1a + z1b, z2 = z2a + z2b;
-        // inclusive scan over the 64 chunks of this wave: Z_l = z_l + P Z_{l-1}
+        __syncthreads();                      // waits for the DMA (vmcnt) and publishes the image
+        const int sw = (t >> 1) & 7;
 #pragma unroll
-        for (int lev = 0; lev < 6; ++lev) {
-            const int d = 1 << lev;
-            const float u1 = __shfl_up(z1, d, 64);
-            const float u2 = __shfl_up(z2, d, 64);
-            const float p00 = sp.plev[lev][0], p01 = sp.plev[lev][1], p10 = sp.plev[lev][2], p11 = sp.plev[lev][3];
-            if (lane >= d) {
-                z1 = __builtin_fmaf(p00, u1, __builtin_fmaf(p01, u2, z1));
-                z2 = __builtin_fmaf(p10, u1, __builtin_fmaf(p11, u2, z2));
+        for (int g = 0; g < 8; ++g) {
+            const float4 w = wint[(8 * h + g) * 256 + t];
+            const float4 q = lds4[t * 8 + (g ^ sw)];
+            if (h == 0) {
+                d[4 * g + 0].x = q.x * w.x;
+                d[4 * g + 1].x = q.y * w.y;
+                d[4 * g + 2].x = q.z * w.z;
+                d[4 * g + 3].x = q.w * w.w;
+            } else {
+                d[4 * g + 0].y = q.x * w.x;
+                d[4 * g + 1].y = q.y * w.y;
+                d[4 * g + 2].y = q.z * w.z;
+                d[4 * g + 3].y = q.w * w.w;
             }
         }
-        if (lane == 63) scr[s * 4 + wave] = make_float2(z1, z2);
-        __syncthreads();
-        // state at the start of this wave's first chunk
-        float c1 = 0.f, c2 = 0.f;
-        for (int u = 0; u < wave; ++u) {
-            const float2 tt = scr[s * 4 + u];
-            const float n1 = __builtin_fmaf(sp.p64[0], c1, __builtin_fmaf(sp.p64[1], c2, tt.x));
-            const float n2 = __builtin_fmaf(sp.p64[2], c1, __builtin_fmaf(sp.p64[3], c2, tt.y));
-            c1 = n1;
-            c2 = n2;
-        }
-        float e1 = __shfl_up(z1, 1, 64), e2 = __shfl_up(z2, 1, 64);
-        if (lane == 0) {
-            e1 = 0.f;
-            e2 = 0.f;
-        }
-        const float4 pp = *reinterpret_cast<const float4 *>(&sp.ppow[lane][0]);
-        float s1 = __builtin_fmaf(pp.x, c1, __builtin_fmaf(pp.y, c2, e1));
-        float s2 = __builtin_fmaf(pp.z, c1, __builtin_fmaf(pp.w, c2, e2));
-        // exact DF2T recursion from the scanned state
-        const float b0 = sp.c[0], b1 = sp.c[1], b2 = sp.c[2], na1 = -sp.c[3], na2 = -sp.c[4];
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const float x = v[j];
-            const float y = __builtin_fmaf(b0, x, s1);
-            s1 = __builtin_fmaf(na1, y, __builtin_fmaf(b1, x, s2));
-            s2 = __builtin_fmaf(na2, y, b2 * x);
-            v[j] = y;
-        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split step of the packed real FFT for the bin pair (k, 8192-k) and the output write.
-//   Xe = Z[k] + conj Z[M-k],  Xo = -i (Z[k] - conj Z[M-k]),  X[k] = Xe + W_N^k Xo,  X[M-k] = conj(Xe - W_N^k Xo)
-// (the 1/2 of the textbook form is already in the window table).
-template <int OUT>
-__device__ __forceinline__ void split_pair(const cf *ldc, const float2 *__restrict__ twP, void *__restrict__ out,
-                                           int f, int k)
+// One cascade section, in place on the thread's two chunks.
+//   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
+//   z1,z2 (out): the same for the NEXT section (accumulated while this section's outputs appear)
+template <bool PREDICT_NEXT>
+__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float4 *mt_next,
+                                            const float4 lanep, float2 *scr_s, int lane, int wave, v2f &z1, v2f &z2)
 {
-    const int km = (SA_MC - k) & (SA_MC - 1);
-    const cf zk = ldc[k + (k >> 5)];
-    const cf zm = ldc[km + (km >> 5)];
-    const float2 w = twP[k];
-    const float xer = zk.x + zm.x, xei = zk.y - zm.y;
-    const float xor_ = zk.y + zm.y, xoi = zm.x - zk.x;
-    const float tr = __builtin_fmaf(w.x, xor_, -w.y * xoi);
-    const float ti = __builtin_fmaf(w.x, xoi, w.y * xor_);
-    const float pr = xer + tr, pi = xei + ti;               // X[k]
-    const float qr = xer - tr, qi = xei - ti;               // conj X[M-k]
+    // state after both chunks of this thread, from zero state: zT = Pc zA + zB
+    float t1 = __builtin_fmaf(k.pc[0], z1.x, __builtin_fmaf(k.pc[1], z2.x, z1.y));
+    float t2 = __builtin_fmaf(k.pc[2], z1.x, __builtin_fmaf(k.pc[3], z2.x, z2.y));
+    // inclusive affine scan inside the 16-lane row
+    scan_level<1>(t1, t2, k.plev[0]);
+    scan_level<2>(t1, t2, k.plev[1]);
+    scan_level<4>(t1, t2, k.plev[2]);
+    scan_level<8>(t1, t2, k.plev[3]);
+    const int row = 4 * wave + (lane >> 4);
+    if ((lane & 15) == 15) scr_s[row] = make_float2(t1, t2);
+    const float e1 = row_shr<1>(t1), e2 = row_shr<1>(t2);       // exclusive: state before this thread, row-local
+    __syncthreads();
+    // scan over the 16 row totals (every row of every wave repeats it: 16 lanes, 4 DPP levels)
+    const float2 tt = scr_s[lane & 15];
+    float r1 = tt.x, r2 = tt.y;
+    scan_level<1>(r1, r2, k.prow[0]);
+    scan_level<2>(r1, r2, k.prow[1]);
+    scan_level<4>(r1, r2, k.prow[2]);
+    scan_level<8>(r1, r2, k.prow[3]);
+    // state at the start of this lane's row = inclusive result of the previous row
+    const int src = (lane & 48) | ((row - 1) & 15);
+    float c1 = lane_get(r1, src), c2 = lane_get(r2, src);
+    if (row == 0) {
+        c1 = 0.f;
+        c2 = 0.f;
+    }
+    // start state of chunk A: row-local part + P2^i * (row start state); chunk B: Pc sA + zA
+    const float a1s = __builtin_fmaf(lanep.x, c1, __builtin_fmaf(lanep.y, c2, e1));
+    const float a2s = __builtin_fmaf(lanep.z, c1, __builtin_fmaf(lanep.w, c2, e2));
+    const float b1s = __builtin_fmaf(k.pc[0], a1s, __builtin_fmaf(k.pc[1], a2s, z1.x));
+    const float b2s = __builtin_fmaf(k.pc[2], a1s, __builtin_fmaf(k.pc[3], a2s, z2.x));
+    v2f s1 = {a1s, b1s}, s2 = {a2s, b2s};
+    const float b0 = k.c[0], b1 = k.c[1], b2 = k.c[2], na1 = -k.c[3], na2 = -k.c[4];
+    v2f n1 = {0.f, 0.f}, n2 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+        float4 mm = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PREDICT_NEXT) mm = mt_next[j >> 1];          // wave-uniform LDS broadcast
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const v2f x = d[j + e];
+            const v2f y = b0 * x + s1;
+            s1 = na1 * y + (b1 * x + s2);
+            s2 = na2 * y + b2 * x;
+            d[j + e] = y;
+            if constexpr (PREDICT_NEXT) {
+                n1 += (e == 0 ? mm.x : mm.z) * y;
+                n2 += (e == 0 ? mm.y : mm.w) * y;
+            }
+        }
+    }
+    z1 = n1;
+    z2 = n2;
+}
+
+template <int S>
+__device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
+                                             const float4 *mtab, float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
+{
+    if constexpr (S < SA_MAXSEC) {
+        if (S < ka.nsec) {
+            const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
+            if constexpr (S + 1 < SA_MAXSEC)
+                iir_section<true>(d, ka.sec[S], mtab + 16 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
+            else
+                iir_section<false>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
+            iir_sections<S + 1>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
+        }
+    }
+}
+
+// mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][16] float4 = (m1[j],m2[j],m1[j+1],m2[j+1])
+__device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
+                                            const float4 *mtab, float2 *scr, int t)
+{
+    // predictor for the first section (later ones are fused into the recursion loops)
+    v2f z1 = {0.f, 0.f}, z2 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+        const float4 mm = mtab[j >> 1];
+        z1 += mm.x * d[j];
+        z2 += mm.y * d[j];
+        z1 += mm.z * d[j + 1];
+        z2 += mm.w * d[j + 1];
+    }
+    iir_sections<0>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
+}
+
+// copy the predictor taps into LDS (first 96 threads, one 16-byte load each); visible to everybody
+// after the first barrier of stage_in_chunks
+__device__ __forceinline__ void load_mtab(const SaIirLaneTab *__restrict__ lt, float4 *mtab, int t)
+{
+    if (t < SA_MAXSEC * SA_CHUNK * 2 / 4) mtab[t] = reinterpret_cast<const float4 *>(&lt->m[0][0][0])[t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split step of the packed real FFT for the bin pair (k, 8192-k):
+//   Xe = Z[k] + conj Z[M-k],  Xo = -i (Z[k] - conj Z[M-k]),  X[k] = Xe + W_N^k Xo,  X[M-k] = conj(Xe - W_N^k Xo)
+// (the 1/2 of the textbook form is already in the window table).  Returns P = X[k], Q = conj X[M-k].
+__device__ __forceinline__ void split_eval(const cf zk, const cf zm, const cf w, cf &P, cf &Q)
+{
+    const cf xe = {zk.x + zm.x, zk.y - zm.y};
+    const cf xo = {zk.y + zm.y, zm.x - zk.x};
+    const cf tw = safft::cmul(xo, w);
+    P = xe + tw;
+    Q = xe - tw;
+}
+
+__device__ __forceinline__ float cabs_fast(const cf v) { return fast_sqrt(__builtin_fmaf(v.x, v.x, v.y * v.y)); }
+
+// Output of one group of bins k0..k0+4 (k0 = 4g).  The group evaluates five pairs so that all four
+// output streams (bins k, 8192-k and their mirrors 16384-k, 8192+k) leave as aligned 16-byte stores:
+//   [k0 .. k0+3] = |P0..3|        [16384-k0-4 .. ] = |P4..1|
+//   [8192+k0 ..] = |Q0..3|        [8192-k0-4 ..  ] = |Q4..1|
+// Every bin of the frame is written exactly once over the 1024 groups.
+template <int OUT>
+__device__ __forceinline__ void split_store(const cf (&P)[5], const cf (&Q)[5], void *__restrict__ out, int f, int k0)
+{
     if constexpr (OUT == SA_OUT_MAG_FULL) {
         float *o = reinterpret_cast<float *>(out) + (size_t)f * SA_NPTS;
-        const float mp = fast_sqrt(__builtin_fmaf(pr, pr, pi * pi));
-        const float mq = fast_sqrt(__builtin_fmaf(qr, qr, qi * qi));
-        o[k] = mp;
-        o[SA_MC - k] = mq;
-        o[SA_MC + k] = mq;
-        if (k != 0) o[SA_NPTS - k] = mp;
+        float mp[5], mq[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            mp[e] = cabs_fast(P[e]);
+            mq[e] = cabs_fast(Q[e]);
+        }
+        *reinterpret_cast<float4 *>(o + k0) = make_float4(mp[0], mp[1], mp[2], mp[3]);
+        *reinterpret_cast<float4 *>(o + SA_NPTS - k0 - 4) = make_float4(mp[4], mp[3], mp[2], mp[1]);
+        *reinterpret_cast<float4 *>(o + SA_MC + k0) = make_float4(mq[0], mq[1], mq[2], mq[3]);
+        *reinterpret_cast<float4 *>(o + SA_MC - k0 - 4) = make_float4(mq[4], mq[3], mq[2], mq[1]);
     } else if constexpr (OUT == SA_OUT_MAG_HALF) {
-        float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);
-        o[k] = fast_sqrt(__builtin_fmaf(pr, pr, pi * pi));
-        o[SA_MC - k] = fast_sqrt(__builtin_fmaf(qr, qr, qi * qi));
+        float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);     // rows are not 16-byte aligned
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[k0 + e] = cabs_fast(P[e]);
+#pragma unroll
+        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = cabs_fast(Q[e]);
+        if (k0 == 0) o[SA_MC] = cabs_fast(Q[0]);
     } else {
         float2 *o = reinterpret_cast<float2 *>(out) + (size_t)f * (SA_MC + 1);
-        o[k] = make_float2(pr, pi);
-        o[SA_MC - k] = make_float2(qr, -qi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[k0 + e] = make_float2(P[e].x, P[e].y);
+#pragma unroll
+        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = make_float2(Q[e].x, -Q[e].y);
+        if (k0 == 0) o[SA_MC] = make_float2(Q[0].x, -Q[0].y);
     }
+}
+
+// position of Z[k] inside the half image of the natural-order exchange (round = half of d = k>>9:
+// round 0 holds d in {0..3, 12..15}, round 1 holds d in {4..11}; both map d to d' = 0..7)
+__device__ __forceinline__ int zpos(int k, int round)
+{
+    const int dd = ((k >> 9) + 4 * round) & 7;
+    const int rest = k & 511;
+    return rest + (rest >> 5) + 528 * dd;
 }
 
 // ---------------------------------------------------------------------------------------------
 template <bool IIR, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void chain_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float *__restrict__ win,
-                                                                 const float2 *__restrict__ twA,
-                                                                 const float2 *__restrict__ twB,
+                                                                 const float4 *__restrict__ wint,
+                                                                 const float4 *__restrict__ twA,
+                                                                 const float4 *__restrict__ twB,
                                                                  const float2 *__restrict__ twP,
-                                                                 const SaIirPlan *__restrict__ plan)
+                                                                 const SaIirLaneTab *__restrict__ lanetab,
+                                                                 const SaIirK ka)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf *ldc = reinterpret_cast<cf *>(smem);
-    float4 *lds4 = reinterpret_cast<float4 *>(smem);
-    float2 *scr = reinterpret_cast<float2 *>(smem + kLdsComplex * 8);
+    float2 *scr = reinterpret_cast<float2 *>(smem + kScrOff);
+    cf *side = reinterpret_cast<cf *>(smem + kSideOff);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
+    const int lo = lane & 15;          // b in pass B, c in pass C
+    const int kq = lane >> 4;
+    // one frame per workgroup: no loop => no loop-invariant address hoisting (which spilled)
+    const int f = blockIdx.x;
+    if (f >= batch) return;
+    const float *xin = in + (size_t)f * SA_NPTS;
+    cf a[32];
+    SA_STAMP(0);
 
-    {
-        // one frame per workgroup: no loop => no loop-invariant address hoisting (which spilled)
-        const int f = blockIdx.x;
-        if (f >= batch) return;
-        const float *xin = in + (size_t)f * SA_NPTS;
-        cf a[32];
-
-        if constexpr (IIR) {
-            float v[64];
-            stage_in_chunks(xin, win, lds4, t, v);
-            iir_cascade(v, plan, scr, t);
-            // exchange: chunk layout -> pass-A layout (index + index/32 padding)
+    if constexpr (IIR) {
+        v2f d[32];
+        float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
+        load_mtab(lanetab, mtab, t);
+        stage_in_chunks(xin, wint, smem, t, d);
+        SA_STAMP(1);
+        iir_cascade(d, ka, lanetab, mtab, scr, t);
+        SA_STAMP(2);
+        // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
+        // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].
 #pragma unroll
-            for (int j = 0; j < 32; ++j) ldc[33 * t + j] = {v[2 * j], v[2 * j + 1]};
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if ((t >> 7) == h) {
+                const int tp = t & 127;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ldc[33 * tp + j] = {d[2 * j].x, d[2 * j + 1].x};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ldc[33 * tp + 16 + j] = {d[2 * j].y, d[2 * j + 1].y};
+            }
             __syncthreads();
 #pragma unroll
-            for (int m1 = 0; m1 < 32; ++m1) a[safft::brev(m1, 5)] = ldc[264 * m1 + t + (t >> 5)];
-        } else {
-            const float2 *x2 = reinterpret_cast<const float2 *>(xin);
-            const float2 *w2 = reinterpret_cast<const float2 *>(win);
-#pragma unroll
-            for (int m1 = 0; m1 < 32; ++m1) {
-                const float2 xv = x2[256 * m1 + t];
-                const float2 wv = w2[256 * m1 + t];
-                a[safft::brev(m1, 5)] = {xv.x * wv.x, xv.y * wv.y};
-            }
+            for (int m = 0; m < 16; ++m)
+                a[safft::brev(16 * h + m, 5)] = ldc[264 * m + 33 * (t >> 5) + (t & 31)];
         }
+    } else {
+        const float2 *x2 = reinterpret_cast<const float2 *>(xin);
+        const float2 *w2 = reinterpret_cast<const float2 *>(win);
+#pragma unroll
+        for (int m1 = 0; m1 < 32; ++m1) {
+            const float2 xv = x2[256 * m1 + t];
+            const float2 wv = w2[256 * m1 + t];
+            a[safft::brev(m1, 5)] = {xv.x * wv.x, xv.y * wv.y};
+        }
+    }
 
-        // ---- pass A: 32-point FFT over m1 (stride 256), then twiddle W_8192^(k1*m2), m2 = t
-        safft::fft_dit<32>(a);
+    // ---- pass A: 32-point FFT over m1 (stride 256), then twiddle W_8192^(k1*m2), m2 = t
+    SA_STAMP(3);
+    safft::fft_dit<32>(a);
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) {
-            const float2 w = twA[k1 * 256 + t];
-            a[k1] = safft::cmul(a[k1], {w.x, w.y});
-        }
-        __syncthreads();   // every read of the previous LDS image is done
+    for (int pp = 0; pp < 16; ++pp) {                      // twA4[pp][t] = (W^(2pp * t), W^((2pp+1) * t))
+        const float4 w = twA[pp * 256 + t];
+        if (pp > 0) a[2 * pp] = safft::cmul(a[2 * pp], {w.x, w.y});
+        a[2 * pp + 1] = safft::cmul(a[2 * pp + 1], {w.z, w.w});
+    }
+    SA_STAMP(4);
+    // ---- exchange A -> B in two rounds of 16 rows; FFT q of a thread lives in round q:
+    //      k1 = 16q + 4 wave + kq, b = lo; inputs ldc[row][16 a + b] with row pitch 272
+    cf p[2][16];
 #pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) ldc[k1 * 272 + t] = a[k1];
+    for (int q = 0; q < 2; ++q) {
+        __syncthreads();                                   // previous image fully consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ldc[r * 272 + t] = a[16 * q + r];
         __syncthreads();
-
-        // ---- pass B: for (k1, b): 16-point FFT over a (m2 = 16a + b), twiddle W_256^(b*c)
-        const int lo = lane & 15;          // b in pass B, c in pass C
-        const int kq = lane >> 4;
-        cf p[2][16];
+        const int row = 4 * wave + kq;
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa) p[q][safft::brev(aa, 4)] = ldc[row * 272 + 16 * aa + lo];
+    }
+    SA_STAMP(5);
+    // ---- pass B: 16-point FFT over a, twiddle W_256^(b*c)
+    safft::fft_dit<16>(p[0]);
+    safft::fft_dit<16>(p[1]);
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {                       // twB4[pp][b] = (W_256^(2pp * b), W_256^((2pp+1) * b))
+        const float4 w = twB[pp * 16 + lo];
+        if (pp > 0) {
+            p[0][2 * pp] = safft::cmul(p[0][2 * pp], {w.x, w.y});
+            p[1][2 * pp] = safft::cmul(p[1][2 * pp], {w.x, w.y});
+        }
+        p[0][2 * pp + 1] = safft::cmul(p[0][2 * pp + 1], {w.z, w.w});
+        p[1][2 * pp + 1] = safft::cmul(p[1][2 * pp + 1], {w.z, w.w});
+    }
+    SA_STAMP(6);
+    // ---- exchange B -> C: a 16x16 transpose inside each 16-lane group, through the row this group
+    //      just read (pitch 17).  Only these 16 lanes touch the row: no workgroup barrier; the LDS
+    //      executes a wave's accesses in order.
+    {
+        const int base = (4 * wave + kq) * 272;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int k1 = 8 * wave + 4 * q + kq;
-#pragma unroll
-            for (int aa = 0; aa < 16; ++aa) p[q][safft::brev(aa, 4)] = ldc[k1 * 272 + 16 * aa + lo];
-        }
-        safft::fft_dit<16>(p[0]);
-        safft::fft_dit<16>(p[1]);
-#pragma unroll
-        for (int c = 1; c < 16; ++c) {
-            const float2 w = twB[c * 16 + lo];
-            p[0][c] = safft::cmul(p[0][c], {w.x, w.y});
-            p[1][c] = safft::cmul(p[1][c], {w.x, w.y});
-        }
-        __syncthreads();   // all pass-B reads done before the image is overwritten
-        // exchange inside each 16-lane group: [k1][c][b] with row pitch 17
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int base = (8 * wave + 4 * q + kq) * 272;
 #pragma unroll
             for (int c = 0; c < 16; ++c) ldc[base + c * 17 + lo] = p[q][c];
-        }
-        __syncthreads();
-        // ---- pass C: for (k1, c): 16-point FFT over b -> d;  Z[k1 + 32c + 512d]
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int base = (8 * wave + 4 * q + kq) * 272;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int b = 0; b < 16; ++b) p[q][safft::brev(b, 4)] = ldc[base + lo * 17 + b];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        safft::fft_dit<16>(p[0]);
-        safft::fft_dit<16>(p[1]);
+    }
+    SA_STAMP(7);
+    // ---- pass C: 16-point FFT over b -> d;  Z[k1 + 32c + 512d], k1 = 16q + 4 wave + kq, c = lo
+    safft::fft_dit<16>(p[0]);
+    safft::fft_dit<16>(p[1]);
+    SA_STAMP(8);
+    // ---- natural-order image + split step, two rounds: round 0 = d in {0..3,12..15} (bins k < 2048
+    //      and their partners), round 1 = d in {4..11}.  Z[2048] and Z[6144] sit on the seam and
+    //      travel through two side slots.
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
         __syncthreads();
-        // natural-order image of Z with index + index/32 padding
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int k1 = 8 * wave + 4 * q + kq;
+            const int k1 = 16 * q + 4 * wave + kq;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) ldc[k1 + 33 * lo + 528 * d] = p[q][d];
+            for (int dd = 0; dd < 8; ++dd) {
+                const int dsel = (r == 0) ? (dd < 4 ? dd : dd + 8) : dd + 4;
+                ldc[k1 + 33 * lo + 528 * dd] = p[q][dsel];
+            }
+        }
+        if (r == 0 && t == 0) {                               // k1 = 0, c = 0: d = 12 and d = 4
+            side[0] = p[0][12];
+            side[1] = p[0][4];
         }
         __syncthreads();
-
-        // ---- split step + output.  Pair (k, 8192-k), k = t + 256j; thread 0 also takes k = 4096.
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) split_pair<OUT>(ldc, twP, out, f, t + 256 * j);
-        if (t == 0) split_pair<OUT>(ldc, twP, out, f, 4096);
+        SA_STAMP(9 + r);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int k0 = 4 * (t + 256 * jj + 512 * r);
+            const float4 w01 = *reinterpret_cast<const float4 *>(twP + k0);
+            const float4 w23 = *reinterpret_cast<const float4 *>(twP + k0 + 2);
+            const float2 w4 = twP[k0 + 4];
+            const cf w[5] = {{w01.x, w01.y}, {w01.z, w01.w}, {w23.x, w23.y}, {w23.z, w23.w}, {w4.x, w4.y}};
+            cf P[5], Q[5];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                const int k = k0 + e;
+                const int km = (SA_MC - k) & (SA_MC - 1);
+                cf zk = ldc[zpos(k, r)];
+                cf zm = ldc[zpos(km, r)];
+                if (r == 0 && k == 2048) zk = side[1];
+                if (km == 6144) zm = side[0];
+                split_eval(zk, zm, w[e], P[e], Q[e]);
+            }
+            split_store<OUT>(P, Q, out, f, k0);
+        }
     }
+    SA_STAMP(11);
+#ifdef SA_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);      // drain the stores so the last stamp sees them retire
+#endif
+    SA_STAMP(12);
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
 template <bool IIR>
-__global__ __launch_bounds__(kThreads, 2) void time_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__restrict__ in,
                                                                 float *__restrict__ out, int batch,
-                                                                const float *__restrict__ win,
-                                                                const SaIirPlan *__restrict__ plan)
+                                                                const float4 *__restrict__ wint,
+                                                                const SaIirLaneTab *__restrict__ lanetab,
+                                                                const SaIirK ka)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *lds4 = reinterpret_cast<float4 *>(smem);
-    float2 *scr = reinterpret_cast<float2 *>(smem + kLdsComplex * 8);
+    float2 *scr = reinterpret_cast<float2 *>(smem + kScrOff);
     const int t = threadIdx.x;
-    {
-        const int f = blockIdx.x;
-        if (f >= batch) return;
-        float v[64];
-        stage_in_chunks(in + (size_t)f * SA_NPTS, win, lds4, t, v);
-        if constexpr (IIR) iir_cascade(v, plan, scr, t);
-        float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
+    const int f = blockIdx.x;
+    if (f >= batch) return;
+    v2f d[32];
+    float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
+    if constexpr (IIR) load_mtab(lanetab, mtab, t);
+    stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
+    if constexpr (IIR) iir_cascade(d, ka, lanetab, mtab, scr, t);
+    float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)   // undo the folded 1/2 (exact)
-            o4[j] = make_float4(2.f * v[4 * j], 2.f * v[4 * j + 1], 2.f * v[4 * j + 2], 2.f * v[4 * j + 3]);
+    for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)
+        o4[g] = make_float4(2.f * d[4 * g].x, 2.f * d[4 * g + 1].x, 2.f * d[4 * g + 2].x, 2.f * d[4 * g + 3].x);
+        o4[g + 8] = make_float4(2.f * d[4 * g].y, 2.f * d[4 * g + 1].y, 2.f * d[4 * g + 2].y, 2.f * d[4 * g + 3].y);
     }
 }
 
@@ -308,19 +499,29 @@ hipError_t set_lds(K kernel)
 
 }  // namespace
 
-hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, bool iir,
-                               const SaF32Tables &tb, hipStream_t stream)
+#ifdef SA_STAMPS
+extern "C" int sa_debug_set_stamps(void *p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stamps), &p, sizeof(p));
+}
+#endif
+
+hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
+                               hipStream_t stream)
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid(batch), block(kThreads);
     hipError_t e = hipSuccess;
+    static const SaIirK kNoIir = {};
+    const bool iir = tb.iir != nullptr && tb.iir->nsec > 0;
+    const SaIirK &ka = iir ? *tb.iir : kNoIir;
 #define SA_LAUNCH(IIRF, OUTK)                                                                          \
     do {                                                                                               \
         auto kern = chain_f32_kernel<IIRF, OUTK>;                                                      \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_half, tb.twA, \
-                           tb.twB, tb.twP, tb.plan);                                                   \
+        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_half, tb.win_t, tb.twA, \
+                           tb.twB, tb.twP, tb.lanetab, ka);                                            \
     } while (0)
     if (out_kind == SA_OUT_TIME) {
         if (iir) {
@@ -328,13 +529,13 @@ hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_ki
             e = set_lds(kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, reinterpret_cast<float *>(out), batch,
-                               tb.win_half, tb.plan);
+                               tb.win_t, tb.lanetab, ka);
         } else {
             auto kern = time_f32_kernel<false>;
             e = set_lds(kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, reinterpret_cast<float *>(out), batch,
-                               tb.win_half, tb.plan);
+                               tb.win_t, tb.lanetab, ka);
         }
     } else if (iir) {
         switch (out_kind) {

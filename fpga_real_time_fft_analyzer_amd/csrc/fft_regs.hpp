@@ -1,20 +1,22 @@
 // fft_regs.hpp -- small power-of-two FFTs held entirely in VGPRs (gfx950).
 //
-// A thread owns R complex points in registers.  The transform is decimation-in-time, radix 2,
-// with the input placed in bit-reversed slots by the caller (free: the caller chooses which
-// slot each LDS/global load lands in), so the output comes out in natural order.  Every
-// twiddle is a compile-time constant; a butterfly costs 6 FMAs (a' = a + w*b as two FMA
-// chains, b' = 2a - a'), 4 adds for w = 1 and w = -i.  All indices are compile-time so the
-// arrays never leave registers (cdna_hip_programming.md section 5.4 rule 20).
+// A thread owns R complex points in registers, each a packed float pair (re, im) so that the
+// arithmetic maps onto the packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_fma_f32): gfx950
+// issues a wave64 VALU instruction in 4 cycles whether it carries one or two floats per lane.
+// The transform is decimation-in-time, radix 2, with the input placed in bit-reversed slots by the
+// caller (free: the caller chooses which slot each LDS/global load lands in), so the output comes
+// out in natural order.  Every twiddle is a compile-time constant; a butterfly costs 3 packed FMAs
+// (a' = a + w*b as two FMAs, b' = 2a - a'), 2 packed adds for w = 1 and w = -i.  All indices are
+// compile-time so the arrays never leave registers (cdna_hip_programming.md section 5.4 rule 20).
+//
+// The functions are __host__ __device__ so tests/cpp/test_fft_regs.cpp can check them on the CPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
 
 namespace safft {
 
-struct cf {
-    float x, y;
-};
+typedef float cf __attribute__((ext_vector_type(2)));   // (re, im)
 
 __host__ __device__ constexpr int brev(int v, int bits)
 {
@@ -49,35 +51,40 @@ __host__ __device__ constexpr float cos32(int m)
 
 __host__ __device__ constexpr float sin32(int m) { return cos32(m - 8); }
 
+__host__ __device__ __forceinline__ cf swap_ri(cf v) { return __builtin_shufflevector(v, v, 1, 0); }
+__host__ __device__ __forceinline__ cf pk_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+
 // a' = a + W*b, b' = a - W*b with W = exp(-2*pi*i*M32/32)
 template <int M32>
-__device__ __forceinline__ void bfly(cf &a, cf &b)
+__host__ __device__ __forceinline__ void bfly(cf &a, cf &b)
 {
     if constexpr (M32 == 0) {
         const cf t = b;
-        b = {a.x - t.x, a.y - t.y};
-        a = {a.x + t.x, a.y + t.y};
+        b = a - t;
+        a = a + t;
     } else if constexpr (M32 == 8) {          // W = -i : W*b = (b.y, -b.x)
         const cf t = {b.y, -b.x};
-        b = {a.x - t.x, a.y - t.y};
-        a = {a.x + t.x, a.y + t.y};
+        b = a - t;
+        a = a + t;
     } else {
         constexpr float wr = cos32(M32), wi = -sin32(M32);
-        const float nr = __builtin_fmaf(wr, b.x, __builtin_fmaf(-wi, b.y, a.x));
-        const float ni = __builtin_fmaf(wr, b.y, __builtin_fmaf(wi, b.x, a.y));
-        b = {__builtin_fmaf(2.0f, a.x, -nr), __builtin_fmaf(2.0f, a.y, -ni)};
-        a = {nr, ni};
+        const cf wrr = {wr, wr};
+        const cf wii = {-wi, wi};
+        const cf n = pk_fma(wii, swap_ri(b), pk_fma(wrr, b, a));   // a + W*b
+        const cf two = {2.0f, 2.0f};
+        b = pk_fma(two, a, -n);
+        a = n;
     }
 }
 
 template <int HALF, int... Ks>
-__device__ __forceinline__ void dit_group(cf *a, std::integer_sequence<int, Ks...>)
+__host__ __device__ __forceinline__ void dit_group(cf *a, std::integer_sequence<int, Ks...>)
 {
     (bfly<Ks * (16 / HALF)>(a[Ks], a[Ks + HALF]), ...);
 }
 
 template <int R, int HALF>
-__device__ __forceinline__ void dit_stage(cf (&a)[R])
+__host__ __device__ __forceinline__ void dit_stage(cf (&a)[R])
 {
 #pragma unroll
     for (int g = 0; g < R; g += 2 * HALF) dit_group<HALF>(&a[g], std::make_integer_sequence<int, HALF>{});
@@ -85,7 +92,7 @@ __device__ __forceinline__ void dit_stage(cf (&a)[R])
 
 // in: a[brev(n)] = x[n];  out: a[k] = sum_n x[n] exp(-2*pi*i*n*k/R)
 template <int R>
-__device__ __forceinline__ void fft_dit(cf (&a)[R])
+__host__ __device__ __forceinline__ void fft_dit(cf (&a)[R])
 {
     static_assert(R == 4 || R == 8 || R == 16 || R == 32, "unsupported size");
     dit_stage<R, 1>(a);
@@ -95,9 +102,12 @@ __device__ __forceinline__ void fft_dit(cf (&a)[R])
     if constexpr (R >= 32) dit_stage<R, 16>(a);
 }
 
-__device__ __forceinline__ cf cmul(cf a, cf w)
+// complex product a * w as two packed ops
+__host__ __device__ __forceinline__ cf cmul(cf a, cf w)
 {
-    return {__builtin_fmaf(a.x, w.x, -a.y * w.y), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+    const cf wr = {w.x, w.x};
+    const cf wi = {-w.y, w.y};
+    return pk_fma(wi, swap_ri(a), wr * a);
 }
 
 }  // namespace safft

@@ -5,27 +5,36 @@
 
 #define SA_NPTS 16384          // real samples per frame
 #define SA_MC 8192             // complex points of the packed transform
-#define SA_CHUNK 64            // IIR samples per thread
-#define SA_NCHUNK 256          // chunks per frame = threads per workgroup
+#define SA_CHUNK 32            // IIR samples per chunk; a thread owns two consecutive chunks
+#define SA_NTHREADS 256        // threads per workgroup = chunk pairs per frame
 #define SA_MAXSEC 6
 
 // Float IIR plan: the cascade in "predict / scan / recurse" form.
 // Section s is the transposed-direct-form-II biquad of scipy.signal.sosfilt
 //   y = b0 x + s1;  s1' = b1 x - a1 y + s2;  s2' = b2 x - a2 y
-// with state transition A = [[-a1,1],[-a2,0]], input vector Bv = [b1 - a1 b0, b2 - a2 b0].
-// P = A^64 is the per-chunk transition.
-struct SaIirSecPlan {
+// with state transition A = [[-a1,1],[-a2,0]] and input vector Bv = [b1 - a1 b0, b2 - a2 b0].
+// Pc = A^32 (one chunk), P2 = A^64 (one thread = two chunks), Prow = A^1024 (one 16-lane row).
+// Everything here is wave-uniform and travels in the kernel argument segment (SGPRs).
+struct SaIirSecK {
     float c[8];            // b0,b1,b2,a1,a2,0,0,0
-    float plev[6][4];      // P^(2^i), i = 0..5, row-major p00,p01,p10,p11  (in-wave scan)
-    float p64[4];          // P^64                                          (cross-wave carry)
-    float m[2][SA_CHUNK];  // predictor: state after a chunk from zero state = sum_j m[.][j] x[j]
-    float ppow[64][4];     // P^l, l = 0..63                                (carry injection per lane)
+    float pc[4];           // Pc, row-major p00,p01,p10,p11
+    float plev[4][4];      // P2^(1,2,4,8)      in-row scan (DPP row_shr 1,2,4,8)
+    float prow[4][4];      // Prow^(1,2,4,8)    scan over the 16 rows of a frame
 };
 
-struct SaIirPlan {
+struct SaIirK {
     int nsec;
     int pad[3];
-    SaIirSecPlan sec[SA_MAXSEC];
+    SaIirSecK sec[SA_MAXSEC];
+};
+
+// device-memory part of the plan:
+//   m[s][j]   = predictor taps (m1, m2): chunk end state from zero state = sum_j m[s][j] x[j];
+//               copied into LDS at kernel start and read as wave-uniform broadcasts
+//   p[s][i]   = P2^i, i = lane index inside its 16-lane row (start-state injection per lane)
+struct SaIirLaneTab {
+    float m[SA_MAXSEC][SA_CHUNK][2];
+    float p[SA_MAXSEC][16][4];
 };
 
 // Integer-path parameters passed by value (kernarg => stream-ordered for free).
@@ -42,14 +51,16 @@ struct SaQ15Params {
 // launchers (defined in chain_f32.hip / chain_q15.hip)
 struct SaF32Tables {
     const float *win_half;     // [16384] 0.5 * window
-    const float2 *twA;         // [32][256]  W_8192^(k1*m2)
-    const float2 *twB;         // [16][16]   W_256^(c*b)
+    const float4 *win_t;       // [16][256] the same, transposed: win_t[g][t] = win_half[64t + 4g .. +3]
+    const float4 *twA;         // [16][256]  (W_8192^(2p*m2), W_8192^((2p+1)*m2))
+    const float4 *twB;         // [8][16]    (W_256^(2p*b),   W_256^((2p+1)*b))
     const float2 *twP;         // [4097]     W_16384^k
-    const SaIirPlan *plan;     // device copy (may be null when no IIR)
+    const SaIirLaneTab *lanetab;   // device
+    const SaIirK *iir;             // HOST pointer, copied into the kernel arguments (null = no IIR)
 };
 
-hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, bool iir,
-                               const SaF32Tables &t, hipStream_t stream);
+hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
+                               hipStream_t stream);
 
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM

@@ -29,38 +29,56 @@ inline Mat2 mul(const Mat2 &x, const Mat2 &y)
     return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
 }
 
+inline Mat2 mpow(Mat2 m, int e)
+{
+    Mat2 r = {1, 0, 0, 1};
+    while (e > 0) {
+        if (e & 1) r = mul(r, m);
+        m = mul(m, m);
+        e >>= 1;
+    }
+    return r;
+}
+
+inline void put(float *dst, const Mat2 &m)
+{
+    dst[0] = (float)m.a; dst[1] = (float)m.b; dst[2] = (float)m.c; dst[3] = (float)m.d;
+}
+
 // Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
-void build_plan(const double *sos, int nsec, SaIirPlan *plan)
+void build_plan(const double *sos, int nsec, SaIirK *plan, SaIirLaneTab *lt)
 {
     std::memset(plan, 0, sizeof(*plan));
+    std::memset(lt, 0, sizeof(*lt));
     plan->nsec = nsec;
     for (int s = 0; s < nsec; ++s) {
         const double *r = sos + 6 * s;
         const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
-        SaIirSecPlan &sp = plan->sec[s];
+        SaIirSecK &sp = plan->sec[s];
         sp.c[0] = (float)b0; sp.c[1] = (float)b1; sp.c[2] = (float)b2; sp.c[3] = (float)a1; sp.c[4] = (float)a2;
         const Mat2 A = {-a1, 1.0, -a2, 0.0};
         double v0 = b1 - a1 * b0, v1 = b2 - a2 * b0;      // Bv
-        for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[:, j] = A^(63-j) Bv
-            sp.m[0][j] = (float)v0;
-            sp.m[1][j] = (float)v1;
+        for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[j] = A^(31-j) Bv
+            lt->m[s][j][0] = (float)v0;
+            lt->m[s][j][1] = (float)v1;
             const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
             v0 = n0; v1 = n1;
         }
-        Mat2 P = {1, 0, 0, 1};
-        for (int i = 0; i < SA_CHUNK; ++i) P = mul(P, A);   // P = A^64
-        Mat2 pw = {1, 0, 0, 1};
-        for (int l = 0; l < 64; ++l) {                      // ppow[l] = P^l
-            sp.ppow[l][0] = (float)pw.a; sp.ppow[l][1] = (float)pw.b;
-            sp.ppow[l][2] = (float)pw.c; sp.ppow[l][3] = (float)pw.d;
-            pw = mul(pw, P);
-        }
-        sp.p64[0] = (float)pw.a; sp.p64[1] = (float)pw.b; sp.p64[2] = (float)pw.c; sp.p64[3] = (float)pw.d;
-        Mat2 q = P;
-        for (int i = 0; i < 6; ++i) {                       // plev[i] = P^(2^i)
-            sp.plev[i][0] = (float)q.a; sp.plev[i][1] = (float)q.b;
-            sp.plev[i][2] = (float)q.c; sp.plev[i][3] = (float)q.d;
+        const Mat2 Pc = mpow(A, SA_CHUNK);                  // one chunk
+        const Mat2 P2 = mul(Pc, Pc);                        // one thread (two chunks)
+        const Mat2 Prow = mpow(P2, 16);                     // one 16-lane row
+        put(sp.pc, Pc);
+        Mat2 q = P2, qr = Prow;
+        for (int i = 0; i < 4; ++i) {                       // powers 1,2,4,8
+            put(sp.plev[i], q);
+            put(sp.prow[i], qr);
             q = mul(q, q);
+            qr = mul(qr, qr);
+        }
+        Mat2 pw = {1, 0, 0, 1};
+        for (int i = 0; i < 16; ++i) {                      // lanetab[s][i] = P2^i
+            put(lt->p[s][i], pw);
+            pw = mul(pw, P2);
         }
     }
 }
@@ -92,11 +110,14 @@ struct sa_handle {
     int8_t rx_buf[12] = {0};
     // host tables
     std::vector<int16_t> rom;
-    SaIirPlan plan_default{}, plan_custom{};
+    SaIirK plan_default{}, plan_custom{};
+    SaIirLaneTab lt_default{}, lt_custom{};
     // device tables
     float *d_win_half = nullptr;
-    float2 *d_twA = nullptr, *d_twB = nullptr, *d_twP = nullptr;
-    SaIirPlan *d_plan_default = nullptr, *d_plan_custom = nullptr;
+    float4 *d_win_t = nullptr;
+    float4 *d_twA = nullptr, *d_twB = nullptr;
+    float2 *d_twP = nullptr;
+    SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
     int16_t *d_rom = nullptr;
     uint32_t *d_twq = nullptr;
     int16_t *d_work = nullptr;
@@ -150,17 +171,49 @@ void default_rom(std::vector<int16_t> &rom)
     }
 }
 
+// half = 0.5 * window (exact scaling, undone by the split step).  Two device copies: natural order for
+// the bypass kernel, and transposed (t-major 16-byte units) for the chunk layout of the IIR kernels.
+void transpose_window(const std::vector<float> &half, std::vector<float> &tr)
+{
+    tr.resize(SA_NPTS);
+    for (int t = 0; t < 256; ++t)
+        for (int g = 0; g < 16; ++g)
+            for (int e = 0; e < 4; ++e) tr[(g * 256 + t) * 4 + e] = half[64 * t + 4 * g + e];
+}
+
+int upload_window_half(sa_handle *h, const std::vector<float> &half)
+{
+    std::vector<float> tr;
+    transpose_window(half, tr);
+    const int rc = upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+    if (rc != SA_OK) return rc;
+    return upload(h, h->d_win_t, tr.data(), sizeof(float) * SA_NPTS);
+}
+
 int set_window_f32_from(sa_handle *h, const float *w)
 {
     std::vector<float> half(SA_NPTS);
-    for (int i = 0; i < SA_NPTS; ++i) half[i] = 0.5f * w[i];   // exact; undone by the split step
-    return upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+    for (int i = 0; i < SA_NPTS; ++i) half[i] = 0.5f * w[i];
+    return upload_window_half(h, half);
+}
+
+// flat float view for tests: SaIirK followed by SaIirLaneTab
+int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
+{
+    const int n1 = (int)(sizeof(SaIirK) / sizeof(float)), n2 = (int)(sizeof(SaIirLaneTab) / sizeof(float));
+    if (out && cap > 0) {
+        std::vector<float> tmp(n1 + n2);
+        std::memcpy(tmp.data(), &p, sizeof(SaIirK));
+        std::memcpy(tmp.data() + n1, &lt, sizeof(SaIirLaneTab));
+        std::memcpy(out, tmp.data(), sizeof(float) * (size_t)(cap < n1 + n2 ? cap : n1 + n2));
+    }
+    return n1 + n2;
 }
 
 int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
 {
-    build_plan(sos_norm, nsec, &h->plan_custom);
-    return upload(h, h->d_plan_custom, &h->plan_custom, sizeof(SaIirPlan));
+    build_plan(sos_norm, nsec, &h->plan_custom, &h->lt_custom);
+    return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
 }  // namespace
@@ -194,11 +247,12 @@ int sa_create(int device, sa_handle **out)
     } while (0)
     SA_HIPC(hipSetDevice(device));
     SA_HIPC(hipMalloc(&h->d_win_half, sizeof(float) * SA_NPTS));
-    SA_HIPC(hipMalloc(&h->d_twA, sizeof(float2) * 32 * 256));
-    SA_HIPC(hipMalloc(&h->d_twB, sizeof(float2) * 16 * 16));
-    SA_HIPC(hipMalloc(&h->d_twP, sizeof(float2) * 4097));
-    SA_HIPC(hipMalloc(&h->d_plan_default, sizeof(SaIirPlan)));
-    SA_HIPC(hipMalloc(&h->d_plan_custom, sizeof(SaIirPlan)));
+    SA_HIPC(hipMalloc(&h->d_win_t, sizeof(float) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_twA, sizeof(float4) * 16 * 256));
+    SA_HIPC(hipMalloc(&h->d_twB, sizeof(float4) * 8 * 16));
+    SA_HIPC(hipMalloc(&h->d_twP, sizeof(float2) * 4100));
+    SA_HIPC(hipMalloc(&h->d_lt_default, sizeof(SaIirLaneTab)));
+    SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint32_t) * SA_NPTS));
 
@@ -208,35 +262,41 @@ int sa_create(int device, sa_handle **out)
         default_window_f64(w);
         std::vector<float> half(SA_NPTS);
         for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * w[i]);
+        std::vector<float> tr;
+        transpose_window(half, tr);
         SA_HIPC(hipMemcpy(h->d_win_half, half.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
-        std::vector<float2> ta(32 * 256), tb(16 * 16), tp(4097);
-        for (int k1 = 0; k1 < 32; ++k1)
+        SA_HIPC(hipMemcpy(h->d_win_t, tr.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
+        std::vector<float4> ta(16 * 256), tb(8 * 16);
+        std::vector<float2> tp(4100);
+        for (int pp = 0; pp < 16; ++pp)                    // pairs of twiddle rows: one 16-byte load feeds two points
             for (int m2 = 0; m2 < 256; ++m2) {
-                const double ang = -2.0 * M_PI * (double)(k1 * m2) / 8192.0;
-                ta[k1 * 256 + m2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+                const double a0 = -2.0 * M_PI * (double)(2 * pp * m2) / 8192.0;
+                const double a1 = -2.0 * M_PI * (double)((2 * pp + 1) * m2) / 8192.0;
+                ta[pp * 256 + m2] = make_float4((float)std::cos(a0), (float)std::sin(a0), (float)std::cos(a1), (float)std::sin(a1));
             }
-        for (int c = 0; c < 16; ++c)
+        for (int pp = 0; pp < 8; ++pp)
             for (int b = 0; b < 16; ++b) {
-                const double ang = -2.0 * M_PI * (double)(c * b) / 256.0;
-                tb[c * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+                const double a0 = -2.0 * M_PI * (double)(2 * pp * b) / 256.0;
+                const double a1 = -2.0 * M_PI * (double)((2 * pp + 1) * b) / 256.0;
+                tb[pp * 16 + b] = make_float4((float)std::cos(a0), (float)std::sin(a0), (float)std::cos(a1), (float)std::sin(a1));
             }
-        for (int k = 0; k <= 4096; ++k) {
+        for (int k = 0; k < 4100; ++k) {
             const double ang = -2.0 * M_PI * (double)k / 16384.0;
             tp[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
-        SA_HIPC(hipMemcpy(h->d_twA, ta.data(), sizeof(float2) * ta.size(), hipMemcpyHostToDevice));
-        SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float2) * tb.size(), hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twA, ta.data(), sizeof(float4) * ta.size(), hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float4) * tb.size(), hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_twP, tp.data(), sizeof(float2) * tp.size(), hipMemcpyHostToDevice));
     }
     // IIR plans: default = the fixed ALPHA/BETA cascade as real taps; custom = cleared coefficients
     {
         double sos[36];
         sos_from_q7(kDefaultQ7, sos);
-        build_plan(sos, 6, &h->plan_default);
-        SA_HIPC(hipMemcpy(h->d_plan_default, &h->plan_default, sizeof(SaIirPlan), hipMemcpyHostToDevice));
+        build_plan(sos, 6, &h->plan_default, &h->lt_default);
+        SA_HIPC(hipMemcpy(h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
         sos_from_q7(h->c12_custom, sos);
-        build_plan(sos, 6, &h->plan_custom);
-        SA_HIPC(hipMemcpy(h->d_plan_custom, &h->plan_custom, sizeof(SaIirPlan), hipMemcpyHostToDevice));
+        build_plan(sos, 6, &h->plan_custom, &h->lt_custom);
+        SA_HIPC(hipMemcpy(h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
     }
     // integer tables
     {
@@ -263,11 +323,12 @@ int sa_destroy(sa_handle *h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_win_half);
+    (void)hipFree(h->d_win_t);
     (void)hipFree(h->d_twA);
     (void)hipFree(h->d_twB);
     (void)hipFree(h->d_twP);
-    (void)hipFree(h->d_plan_default);
-    (void)hipFree(h->d_plan_custom);
+    (void)hipFree(h->d_lt_default);
+    (void)hipFree(h->d_lt_custom);
     (void)hipFree(h->d_rom);
     (void)hipFree(h->d_twq);
     (void)hipFree(h->d_work);
@@ -417,7 +478,7 @@ int sa_set_window_f32(sa_handle *h, const float *w)
     default_window_f64(d);
     std::vector<float> half(SA_NPTS);
     for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * d[i]);
-    return upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+    return upload_window_half(h, half);
 }
 
 int sa_set_window_mode_q15(sa_handle *h, int mode)
@@ -488,16 +549,17 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     if (h->filter_mode == SA_FILTER_WIDE)
         return fail(h, SA_ESTATE, "sa_process_f32: filter mode 0xA2 (Q2.14) belongs to the Q15 path; use 0xA1 with sa_load_sos_f32");
     SA_HIP(h, hipSetDevice(h->device));
-    SaF32Tables t = {h->d_win_half, h->d_twA, h->d_twB, h->d_twP, nullptr};
-    bool iir = false;
+    // The section coefficients travel by value in the kernel arguments (stream-ordered by
+    // construction); only the small per-lane table lives in device memory.
+    SaF32Tables t = {h->d_win_half, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, nullptr, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
-        t.plan = h->d_plan_default;
-        iir = true;
+        t.lanetab = h->d_lt_default;
+        t.iir = &h->plan_default;
     } else if (h->filter_mode == SA_FILTER_CUSTOM) {
-        t.plan = h->d_plan_custom;
-        iir = h->plan_custom.nsec > 0;
+        t.lanetab = h->d_lt_custom;
+        t.iir = &h->plan_custom;
     }
-    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, iir, t, (hipStream_t)stream));
+    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, (hipStream_t)stream));
     return SA_OK;
 }
 
@@ -515,10 +577,8 @@ int sa_pack_frame(const int16_t *iq_host, uint8_t *frame_bytes)
 int sa_debug_iir_plan_f32(const sa_handle *h, float *out, int cap)
 {
     if (!h) return SA_EINVAL;
-    const SaIirPlan *p = (h->filter_mode == SA_FILTER_DEFAULT) ? &h->plan_default : &h->plan_custom;
-    const int need = (int)(sizeof(SaIirPlan) / sizeof(float));
-    if (out && cap > 0) std::memcpy(out, p, sizeof(float) * (size_t)(cap < need ? cap : need));
-    return need;
+    const bool def = h->filter_mode == SA_FILTER_DEFAULT;
+    return export_plan(def ? h->plan_default : h->plan_custom, def ? h->lt_default : h->lt_custom, out, cap);
 }
 
 int sa_iir_plan_from_sos(const double *sos, int n_sections, float *out, int cap)
@@ -530,11 +590,10 @@ int sa_iir_plan_from_sos(const double *sos, int n_sections, float *out, int cap)
         if (a0 == 0.0 || !std::isfinite(a0)) return SA_EINVAL;
         for (int i = 0; i < 6; ++i) norm[6 * s + i] = sos[6 * s + i] / a0;
     }
-    SaIirPlan p;
-    build_plan(norm, n_sections, &p);
-    const int need = (int)(sizeof(SaIirPlan) / sizeof(float));
-    if (out && cap > 0) std::memcpy(out, &p, sizeof(float) * (size_t)(cap < need ? cap : need));
-    return need;
+    SaIirK p;
+    SaIirLaneTab lt;
+    build_plan(norm, n_sections, &p, &lt);
+    return export_plan(p, lt, out, cap);
 }
 
 }  // extern "C"

@@ -96,56 +96,73 @@ def test_pack_frame_is_little_endian(hip_lib_built):
 
 # ---- IIR plan algebra: emulate the kernel's predict / scan / recurse in float32 on the CPU
 def _parse_plan(plan):
+    """Flat view written by sa_iir_plan_from_sos: SaIirK (nsec, pad[3], 6 x {c[8], pc[4], plev[4][4],
+    prow[4][4]}) followed by SaIirLaneTab {m[6][32][2], p[6][16][4]}."""
     nsec = int(plan[:1].view(np.int32)[0])
     off, secs = 4, []
     for _ in range(6):
         c = plan[off:off + 8]; off += 8
-        plev = plan[off:off + 24].reshape(6, 4); off += 24
-        p64 = plan[off:off + 4]; off += 4
-        m = plan[off:off + 128].reshape(2, 64); off += 128
-        ppow = plan[off:off + 256].reshape(64, 4); off += 256
-        secs.append((c, plev, p64, m, ppow))
+        pc = plan[off:off + 4]; off += 4
+        plev = plan[off:off + 16].reshape(4, 4); off += 16
+        prow = plan[off:off + 16].reshape(4, 4); off += 16
+        secs.append([c, pc, plev, prow, None])
+    mt = plan[off:off + 6 * 64].reshape(6, 32, 2); off += 6 * 64
+    for i in range(6):
+        secs[i][4] = mt[i]
+    lt = plan[off:off + 6 * 64].reshape(6, 16, 4); off += 6 * 64
     assert off == plan.size
-    return nsec, secs
+    return nsec, secs, lt
+
+
+def _ks(z, mats):
+    """4-level Kogge-Stone affine scan along axis -2 (16 entries), zero fill, float32."""
+    f = np.float32
+    for lev, d in enumerate((1, 2, 4, 8)):
+        p = mats[lev]
+        u = np.zeros_like(z)
+        u[..., d:, :] = z[..., :-d, :]
+        z = np.stack([(z[..., 0] + (p[0] * u[..., 0] + p[1] * u[..., 1])).astype(f),
+                      (z[..., 1] + (p[2] * u[..., 0] + p[3] * u[..., 1])).astype(f)], axis=-1)
+    return z
 
 
 def emulate_chunked_iir(plan, x):
-    """float32 emulation with the kernel's exact structure: per section predict -> Kogge-Stone scan
-    inside each group of 64 chunks -> carry over 4 groups -> DF2T recursion."""
+    """float32 emulation with the kernel's structure: thread t owns samples [64t, 64t+64) as chunks
+    A,B of 32; per section: predict -> in-row scan (16 threads) -> scan over the 16 row totals ->
+    start states -> DF2T recursion on both chunks."""
     f = np.float32
-    nsec, secs = _parse_plan(plan)
-    v = x.astype(f).reshape(256, 64).copy()
+    nsec, secs, lt = _parse_plan(plan)
+    v = x.astype(f).reshape(256, 2, 32).copy()              # [thread][chunk][j]
     for s in range(nsec):
-        c, plev, p64, m, ppow = secs[s]
-        z = np.zeros((256, 2), f)
-        for j in range(64):
-            z[:, 0] += m[0, j] * v[:, j]
-            z[:, 1] += m[1, j] * v[:, j]
-        z = z.reshape(4, 64, 2)
-        for lev in range(6):
-            d = 1 << lev
-            p = plev[lev]
-            u = np.zeros_like(z)
-            u[:, d:, :] = z[:, :-d, :]
-            add0 = p[0] * u[..., 0] + p[1] * u[..., 1]
-            add1 = p[2] * u[..., 0] + p[3] * u[..., 1]
-            z = np.stack([z[..., 0] + add0, z[..., 1] + add1], axis=-1).astype(f)
-        tot = z[:, 63, :]
-        carry = np.zeros((4, 2), f)
-        for w in range(1, 4):
-            pc = carry[w - 1]
-            carry[w] = [p64[0] * pc[0] + p64[1] * pc[1] + tot[w - 1, 0], p64[2] * pc[0] + p64[3] * pc[1] + tot[w - 1, 1]]
-        e = np.zeros_like(z)
-        e[:, 1:, :] = z[:, :-1, :]
-        s1 = (e[..., 0] + ppow[None, :, 0] * carry[:, None, 0] + ppow[None, :, 1] * carry[:, None, 1]).astype(f).reshape(256)
-        s2 = (e[..., 1] + ppow[None, :, 2] * carry[:, None, 0] + ppow[None, :, 3] * carry[:, None, 1]).astype(f).reshape(256)
+        c, pc, plev, prow, m = secs[s]
+        z = np.zeros((256, 2, 2), f)                         # [thread][chunk][state]
+        for j in range(32):
+            z[:, :, 0] += m[j, 0] * v[:, :, j]
+            z[:, :, 1] += m[j, 1] * v[:, :, j]
+        zA, zB = z[:, 0, :], z[:, 1, :]
+        zT = np.stack([pc[0] * zA[:, 0] + pc[1] * zA[:, 1] + zB[:, 0],
+                       pc[2] * zA[:, 0] + pc[3] * zA[:, 1] + zB[:, 1]], axis=-1).astype(f)
+        inc = _ks(zT.reshape(16, 16, 2), plev)               # [row][lane][state]
+        exc = np.zeros_like(inc)
+        exc[:, 1:, :] = inc[:, :-1, :]
+        rows = _ks(inc[:, 15, :].reshape(1, 16, 2), prow)[0]  # inclusive over rows
+        C = np.zeros((16, 2), f)
+        C[1:] = rows[:-1]
+        lp = lt[s]                                            # [16][4]
+        sA = np.stack([exc[..., 0] + lp[None, :, 0] * C[:, None, 0] + lp[None, :, 1] * C[:, None, 1],
+                       exc[..., 1] + lp[None, :, 2] * C[:, None, 0] + lp[None, :, 3] * C[:, None, 1]],
+                      axis=-1).astype(f).reshape(256, 2)
+        sB = np.stack([pc[0] * sA[:, 0] + pc[1] * sA[:, 1] + zA[:, 0],
+                       pc[2] * sA[:, 0] + pc[3] * sA[:, 1] + zA[:, 1]], axis=-1).astype(f)
+        s1 = np.stack([sA[:, 0], sB[:, 0]], axis=1)           # [thread][chunk]
+        s2 = np.stack([sA[:, 1], sB[:, 1]], axis=1)
         b0, b1, b2, a1, a2 = c[:5]
-        for j in range(64):
-            xx = v[:, j]
+        for j in range(32):
+            xx = v[:, :, j]
             y = (b0 * xx + s1).astype(f)
             s1 = (b1 * xx + s2 - a1 * y).astype(f)
             s2 = (b2 * xx - a2 * y).astype(f)
-            v[:, j] = y
+            v[:, :, j] = y
     return v.reshape(-1)
 
 
@@ -155,7 +172,7 @@ def test_iir_plan_reproduces_sosfilt(hip_lib_built, oracle):
     g = load_golden("g3_fp32_frames.npz")
     sos = g["sos"]
     plan = iir_plan_from_sos(sos)
-    assert plan.size == 4 + 6 * (8 + 24 + 4 + 128 + 256)
+    assert plan.size == 4 + 6 * (8 + 4 + 16 + 16 + 64) + 6 * 16 * 4
     hann = oracle.hann_f64()
     for i in range(2):
         xw = (g["x"][i].astype(np.float64) * hann).astype(np.float32)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a workgroup of the fused float kernel spend its cycles?
+
+Loads the SA_STAMPS build (make -C fpga_real_time_fft_analyzer_amd/csrc stamps), runs one batch and
+prints per-phase shader-clock deltas (median over workgroups).  The stamped build serialises what
+the product kernel overlaps: read the SHARES, never its run time (cdna_hip_programming.md section 7).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fpga_real_time_fft_analyzer_amd import abi  # noqa: E402
+
+abi.LIB_PATH = os.path.join(ROOT, "fpga_real_time_fft_analyzer_amd", "libspecan_hip_stamps.so")
+from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
+
+NAMES = ["stage-in (global->LDS->chunk)", "IIR cascade", "exchange to pass A", "FFT32 + twiddle A",
+         "(wait) ", "exchange A->B", "read B", "FFT16x2 + twiddle B", "exchange B->C", "FFT16x2",
+         "exchange to natural", "split + stores issued", "store drain"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    mode = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0xA1
+    ch = SpectrumChain(0)
+    L = abi.lib()
+    L.sa_debug_set_stamps.argtypes = [C.c_void_p]
+    stamps = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+    assert L.sa_debug_set_stamps(stamps.data_ptr()) == 0
+    sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]
+    ch.load_sos(sos)
+    ch.set_filter_mode(mode)
+    x = torch.randn(B, 16384, device="cuda")
+    for _ in range(3):
+        ch.process_f32(x)
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.float64)
+    iir = mode != 0xB1
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12] if iir else [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+    d = np.diff(s[:, idx], axis=1)
+    tot = s[:, 12] - s[:, 0]
+    print(f"B={B} mode=0x{mode:02X}: workgroup lifetime median {np.median(tot):.0f} clk (s_memtime ticks = 100 MHz? see note)")
+    labels = [f"{idx[i]}->{idx[i+1]}" for i in range(len(idx) - 1)]
+    for i, lab in enumerate(labels):
+        print(f"  {lab:7s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}"
+              f"  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
+    span = s[:, 12].max() - s[:, 0].min()
+    print(f"  whole grid span {span:.0f} clk; sum of WG lifetimes / span = {tot.sum() / span:.1f} resident WGs on average")
+
+
+if __name__ == "__main__":
+    main()

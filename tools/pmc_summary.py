@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSV output: per-kernel mean of every counter (last dispatch of each pass)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row.get("Kernel_Name", "")
+            if "chain_f32" not in k and "q15" not in k:
+                continue
+            acc[k.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in acc.items():
+    print("==", k)
+    for c in sorted(d):
+        v = d[c]
+        print(f"   {c:34s} n={len(v):2d}  mean {sum(v)/len(v):16.1f}  last {v[-1]:16.1f}")
