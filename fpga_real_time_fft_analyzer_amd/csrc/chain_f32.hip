@@ -187,23 +187,25 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     z2 = n2;
 }
 
-template <int S>
+// All NSEC sections run unconditionally (the host pads shorter cascades with identity sections,
+// which are exact: y = 1*x + 0).  A run-time section count would carry the 64 data registers
+// through control-flow merges and cost ~190 register copies.
+template <int S, int NSEC>
 __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                              const float4 *mtab, float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
 {
-    if constexpr (S < SA_MAXSEC) {
-        if (S < ka.nsec) {
-            const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
-            if constexpr (S + 1 < SA_MAXSEC)
-                iir_section<true>(d, ka.sec[S], mtab + 16 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
-            else
-                iir_section<false>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
-            iir_sections<S + 1>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
-        }
+    if constexpr (S < NSEC) {
+        const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
+        if constexpr (S + 1 < NSEC)
+            iir_section<true>(d, ka.sec[S], mtab + 16 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
+        else
+            iir_section<false>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
+        iir_sections<S + 1, NSEC>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
     }
 }
 
 // mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][16] float4 = (m1[j],m2[j],m1[j+1],m2[j+1])
+template <int NSEC>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                             const float4 *mtab, float2 *scr, int t)
 {
@@ -217,7 +219,7 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, cons
         z1 += mm.z * d[j + 1];
         z2 += mm.w * d[j + 1];
     }
-    iir_sections<0>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
+    iir_sections<0, NSEC>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
 }
 
 // copy the predictor taps into LDS (first 96 threads, one 16-byte load each); visible to everybody
@@ -289,8 +291,8 @@ __device__ __forceinline__ int zpos(int k, int round)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool IIR, int OUT>
-__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
+template <int NSEC, int OUT>
+__global__ __launch_bounds__(kThreads, NSEC > 0 ? 3 : 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float *__restrict__ win,
                                                                  const float4 *__restrict__ wint,
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     const int f = blockIdx.x;
     if (f >= batch) return;
     const float *xin = in + (size_t)f * SA_NPTS;
+    constexpr bool IIR = NSEC > 0;
     cf a[32];
     SA_STAMP(0);
 
@@ -323,24 +326,33 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
         load_mtab(lanetab, mtab, t);
         stage_in_chunks(xin, wint, smem, t, d);
         SA_STAMP(1);
-        iir_cascade(d, ka, lanetab, mtab, scr, t);
+        iir_cascade<NSEC>(d, ka, lanetab, mtab, scr, t);
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
-        // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].
+        // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
+        // imaginary parts (even / odd samples) live in two float planes: they sit in different
+        // register pairs of d[], and a 64-bit LDS store would need them copied into one pair first.
+        float *ldre = reinterpret_cast<float *>(smem);
+        float *ldim = ldre + 128 * 33;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             __syncthreads();
             if ((t >> 7) == h) {
-                const int tp = t & 127;
+                const int base = 33 * (t & 127);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) ldc[33 * tp + j] = {d[2 * j].x, d[2 * j + 1].x};
-#pragma unroll
-                for (int j = 0; j < 16; ++j) ldc[33 * tp + 16 + j] = {d[2 * j].y, d[2 * j + 1].y};
+                for (int j = 0; j < 16; ++j) {
+                    ldre[base + j] = d[2 * j].x;
+                    ldim[base + j] = d[2 * j + 1].x;
+                    ldre[base + 16 + j] = d[2 * j].y;
+                    ldim[base + 16 + j] = d[2 * j + 1].y;
+                }
             }
             __syncthreads();
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                a[safft::brev(16 * h + m, 5)] = ldc[264 * m + 33 * (t >> 5) + (t & 31)];
+            for (int m = 0; m < 16; ++m) {
+                const int pos = 264 * m + 33 * (t >> 5) + (t & 31);
+                a[safft::brev(16 * h + m, 5)] = {ldre[pos], ldim[pos]};
+            }
         }
     } else {
         const float2 *x2 = reinterpret_cast<const float2 *>(xin);
@@ -465,8 +477,8 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
-template <bool IIR>
-__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__restrict__ in,
+template <int NSEC>
+__global__ __launch_bounds__(kThreads, 3) void time_f32_kernel(const float *__restrict__ in,
                                                                 float *__restrict__ out, int batch,
                                                                 const float4 *__restrict__ wint,
                                                                 const SaIirLaneTab *__restrict__ lanetab,
@@ -479,9 +491,9 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     if (f >= batch) return;
     v2f d[32];
     float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
-    if constexpr (IIR) load_mtab(lanetab, mtab, t);
+    if constexpr (NSEC > 0) load_mtab(lanetab, mtab, t);
     stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
-    if constexpr (IIR) iir_cascade(d, ka, lanetab, mtab, scr, t);
+    if constexpr (NSEC > 0) iir_cascade<NSEC>(d, ka, lanetab, mtab, scr, t);
     float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)
@@ -506,52 +518,55 @@ extern "C" int sa_debug_set_stamps(void *p)
 }
 #endif
 
-hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
-                               hipStream_t stream)
+namespace {
+
+template <int NSEC>
+hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK &ka,
+                       hipStream_t stream)
 {
-    if (batch <= 0) return hipSuccess;
     const dim3 grid(batch), block(kThreads);
     hipError_t e = hipSuccess;
-    static const SaIirK kNoIir = {};
-    const bool iir = tb.iir != nullptr && tb.iir->nsec > 0;
-    const SaIirK &ka = iir ? *tb.iir : kNoIir;
-#define SA_LAUNCH(IIRF, OUTK)                                                                          \
+#define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
-        auto kern = chain_f32_kernel<IIRF, OUTK>;                                                      \
+        auto kern = chain_f32_kernel<NSEC, OUTK>;                                                      \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
         hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_half, tb.win_t, tb.twA, \
                            tb.twB, tb.twP, tb.lanetab, ka);                                            \
     } while (0)
-    if (out_kind == SA_OUT_TIME) {
-        if (iir) {
-            auto kern = time_f32_kernel<true>;
+    switch (out_kind) {
+        case SA_OUT_MAG_FULL: SA_LAUNCH(SA_OUT_MAG_FULL); break;
+        case SA_OUT_MAG_HALF: SA_LAUNCH(SA_OUT_MAG_HALF); break;
+        case SA_OUT_SPEC_HALF: SA_LAUNCH(SA_OUT_SPEC_HALF); break;
+        case SA_OUT_TIME: {
+            auto kern = time_f32_kernel<NSEC>;
             e = set_lds(kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, reinterpret_cast<float *>(out), batch,
                                tb.win_t, tb.lanetab, ka);
-        } else {
-            auto kern = time_f32_kernel<false>;
-            e = set_lds(kern);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, reinterpret_cast<float *>(out), batch,
-                               tb.win_t, tb.lanetab, ka);
+            break;
         }
-    } else if (iir) {
-        switch (out_kind) {
-            case SA_OUT_MAG_FULL: SA_LAUNCH(true, SA_OUT_MAG_FULL); break;
-            case SA_OUT_MAG_HALF: SA_LAUNCH(true, SA_OUT_MAG_HALF); break;
-            case SA_OUT_SPEC_HALF: SA_LAUNCH(true, SA_OUT_SPEC_HALF); break;
-            default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (out_kind) {
-            case SA_OUT_MAG_FULL: SA_LAUNCH(false, SA_OUT_MAG_FULL); break;
-            case SA_OUT_MAG_HALF: SA_LAUNCH(false, SA_OUT_MAG_HALF); break;
-            case SA_OUT_SPEC_HALF: SA_LAUNCH(false, SA_OUT_SPEC_HALF); break;
-            default: return hipErrorInvalidValue;
-        }
+        default: return hipErrorInvalidValue;
     }
 #undef SA_LAUNCH
     return hipGetLastError();
+}
+
+}  // namespace
+
+// tb.iir->nsec is the PADDED section count (0, 2, 4 or 6; see build_plan in specan_abi.cpp).
+hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
+                               hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    static const SaIirK kNoIir = {};
+    const int nsec = tb.iir ? tb.iir->nsec : 0;
+    const SaIirK &ka = nsec > 0 ? *tb.iir : kNoIir;
+    switch (nsec) {
+        case 0: return launch_nsec<0>(in, out, batch, out_kind, tb, ka, stream);
+        case 2: return launch_nsec<2>(in, out, batch, out_kind, tb, ka, stream);
+        case 4: return launch_nsec<4>(in, out, batch, out_kind, tb, ka, stream);
+        case 6: return launch_nsec<6>(in, out, batch, out_kind, tb, ka, stream);
+        default: return hipErrorInvalidValue;
+    }
 }

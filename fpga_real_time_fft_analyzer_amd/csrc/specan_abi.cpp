@@ -46,10 +46,17 @@ inline void put(float *dst, const Mat2 &m)
 }
 
 // Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
-void build_plan(const double *sos, int nsec, SaIirK *plan, SaIirLaneTab *lt)
+// The kernels are compiled for 2, 4 and 6 sections; shorter cascades are padded with identity
+// sections (b0 = 1, rest 0: y = x exactly, all scan matrices and predictor taps come out zero).
+void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *lt)
 {
     std::memset(plan, 0, sizeof(*plan));
     std::memset(lt, 0, sizeof(*lt));
+    const int nsec = nsec_in == 0 ? 0 : (nsec_in <= 2 ? 2 : (nsec_in <= 4 ? 4 : 6));
+    double sos[36];
+    for (int s = 0; s < nsec; ++s)
+        for (int i = 0; i < 6; ++i)
+            sos[6 * s + i] = s < nsec_in ? sos_in[6 * s + i] : ((i == 0 || i == 3) ? 1.0 : 0.0);
     plan->nsec = nsec;
     for (int s = 0; s < nsec; ++s) {
         const double *r = sos + 6 * s;

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""A/B timing of alternative builds of the library in one process, interleaved rounds.
+usage: ab_libs.py libA.so libB.so ...   (paths relative to the package dir)"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "fpga_real_time_fft_analyzer_amd")
+sos = np.ascontiguousarray(np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"], np.float64)
+B = 4096
+gen = torch.Generator(device="cuda").manual_seed(1)
+n = torch.arange(16384, device="cuda", dtype=torch.float32)
+fb = torch.rand(B, 1, generator=gen, device="cuda") * 0.44 + 0.01
+x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, 16384, generator=gen, device="cuda")).contiguous()
+out = torch.empty_like(x)
+libs = []
+for name in sys.argv[1:]:
+    L = C.CDLL(os.path.join(PKG, name))
+    h = C.c_void_p()
+    assert L.sa_create(0, C.byref(h)) == 0
+    L.sa_load_sos_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    L.sa_process_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sa_set_filter_mode.argtypes = [C.c_void_p, C.c_uint8]
+    assert L.sa_load_sos_f64(h, sos.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
+    libs.append((name, L, h))
+st = torch.cuda.current_stream().cuda_stream
+res = {}
+ref = {}
+for mode in (0xA1, 0xB1):
+    for rnd in range(5):
+        for name, L, h in libs:
+            L.sa_set_filter_mode(h, mode)
+            for _ in range(2):
+                L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
+            torch.cuda.synchronize()
+            if rnd == 0:
+                if mode not in ref:
+                    ref[mode] = out.clone()
+                else:
+                    d = (out - ref[mode]).abs().max().item() / ref[mode].abs().max().item()
+                    print(f"   {name} vs {libs[0][0]} mode 0x{mode:02X}: max rel diff {d:.2e}")
+            t0 = time.perf_counter()
+            for _ in range(10):
+                L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
+            torch.cuda.synchronize()
+            res.setdefault((mode, name), []).append((time.perf_counter() - t0) / 10)
+    for name, _, _ in libs:
+        v = sorted(res[(mode, name)])
+        print(f"mode 0x{mode:02X} {name:32s} median {v[len(v)//2]*1e6:8.1f} us  min {v[0]*1e6:8.1f} us  -> {B/v[len(v)//2]/1e6:6.2f} M frames/s")
