@@ -31,7 +31,7 @@ constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange ima
 constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 sections x 16 rows x float2
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
 constexpr int kMtabOff = kSideOff + 16;               // two complex side slots, then the predictor taps
-constexpr int kLdsBytes = kMtabOff + SA_MAXSEC * SA_CHUNK * 2 * 4;
+constexpr int kLdsBytes = kMtabOff + SA_MAXSEC * SA_CHUNK * 4 * 4;   // taps stored as (m1,m1,m2,m2)
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 
@@ -167,20 +167,17 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     const float b0 = k.c[0], b1 = k.c[1], b2 = k.c[2], na1 = -k.c[3], na2 = -k.c[4];
     v2f n1 = {0.f, 0.f}, n2 = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; j += 2) {
-        float4 mm = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (PREDICT_NEXT) mm = mt_next[j >> 1];          // wave-uniform LDS broadcast
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const v2f x = d[j + e];
-            const v2f y = b0 * x + s1;
-            s1 = na1 * y + (b1 * x + s2);
-            s2 = na2 * y + b2 * x;
-            d[j + e] = y;
-            if constexpr (PREDICT_NEXT) {
-                n1 += (e == 0 ? mm.x : mm.z) * y;
-                n2 += (e == 0 ? mm.y : mm.w) * y;
-            }
+    for (int j = 0; j < 32; ++j) {
+        const v2f x = d[j];
+        const v2f y = b0 * x + s1;
+        s1 = na1 * y + (b1 * x + s2);
+        s2 = na2 * y + b2 * x;
+        d[j] = y;
+        if constexpr (PREDICT_NEXT) {
+            const float4 mm = mt_next[j];                     // wave-uniform LDS broadcast (m1,m1,m2,m2)
+            const v2f m1 = {mm.x, mm.y}, m2 = {mm.z, mm.w};
+            n1 = safft::pk_fma(m1, y, n1);
+            n2 = safft::pk_fma(m2, y, n2);
         }
     }
     z1 = n1;
@@ -197,14 +194,14 @@ __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, con
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
         if constexpr (S + 1 < NSEC)
-            iir_section<true>(d, ka.sec[S], mtab + 16 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
+            iir_section<true>(d, ka.sec[S], mtab + 32 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
         else
             iir_section<false>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
         iir_sections<S + 1, NSEC>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
     }
 }
 
-// mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][16] float4 = (m1[j],m2[j],m1[j+1],m2[j+1])
+// mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][32] float4 = (m1[j],m1[j],m2[j],m2[j])
 template <int NSEC>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                             const float4 *mtab, float2 *scr, int t)
@@ -212,21 +209,23 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, cons
     // predictor for the first section (later ones are fused into the recursion loops)
     v2f z1 = {0.f, 0.f}, z2 = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; j += 2) {
-        const float4 mm = mtab[j >> 1];
-        z1 += mm.x * d[j];
-        z2 += mm.y * d[j];
-        z1 += mm.z * d[j + 1];
-        z2 += mm.w * d[j + 1];
+    for (int j = 0; j < 32; ++j) {
+        const float4 mm = mtab[j];
+        const v2f m1 = {mm.x, mm.y}, m2 = {mm.z, mm.w};
+        z1 = safft::pk_fma(m1, d[j], z1);
+        z2 = safft::pk_fma(m2, d[j], z2);
     }
     iir_sections<0, NSEC>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
 }
 
-// copy the predictor taps into LDS (first 96 threads, one 16-byte load each); visible to everybody
-// after the first barrier of stage_in_chunks
+// copy the predictor taps into LDS as (m1,m1,m2,m2) per tap (first 192 threads, one tap each); visible
+// to everybody after the first barrier of stage_in_chunks
 __device__ __forceinline__ void load_mtab(const SaIirLaneTab *__restrict__ lt, float4 *mtab, int t)
 {
-    if (t < SA_MAXSEC * SA_CHUNK * 2 / 4) mtab[t] = reinterpret_cast<const float4 *>(&lt->m[0][0][0])[t];
+    if (t < SA_MAXSEC * SA_CHUNK) {
+        const float2 m = reinterpret_cast<const float2 *>(&lt->m[0][0][0])[t];
+        mtab[t] = make_float4(m.x, m.x, m.y, m.y);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -292,7 +291,7 @@ __device__ __forceinline__ int zpos(int k, int round)
 
 // ---------------------------------------------------------------------------------------------
 template <int NSEC, int OUT>
-__global__ __launch_bounds__(kThreads, NSEC > 0 ? 3 : 4) void chain_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float *__restrict__ win,
                                                                  const float4 *__restrict__ wint,
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(kThreads, NSEC > 0 ? 3 : 4) void chain_f32_kernel(c
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
 template <int NSEC>
-__global__ __launch_bounds__(kThreads, 3) void time_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__restrict__ in,
                                                                 float *__restrict__ out, int batch,
                                                                 const float4 *__restrict__ wint,
                                                                 const SaIirLaneTab *__restrict__ lanetab,
