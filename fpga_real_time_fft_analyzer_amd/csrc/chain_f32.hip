@@ -293,7 +293,7 @@ __device__ __forceinline__ int zpos(int k, int round)
 template <int NSEC, int OUT>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
-                                                                 const float *__restrict__ win,
+                                                                 const float4 *__restrict__ winb,
                                                                  const float4 *__restrict__ wint,
                                                                  const float4 *__restrict__ twA,
                                                                  const float4 *__restrict__ twB,
@@ -354,13 +354,29 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
             }
         }
     } else {
-        const float2 *x2 = reinterpret_cast<const float2 *>(xin);
-        const float2 *w2 = reinterpret_cast<const float2 *>(win);
+        // No IIR: the frame goes HBM -> LDS in natural order (two rounds of 32 KiB, LDS-DMA), and the
+        // thread picks z[256 m1 + t] straight out of the image; the window comes as 16-byte loads of
+        // the pass-A layout (winb[p][t] = window at samples 512(2p)+2t, +1, 512(2p+1)+2t, +1).
+        // 8 + 8 vector-memory instructions per wave and round instead of 32 8-byte loads.
 #pragma unroll
-        for (int m1 = 0; m1 < 32; ++m1) {
-            const float2 xv = x2[256 * m1 + t];
-            const float2 wv = w2[256 * m1 + t];
-            a[safft::brev(m1, 5)] = {xv.x * wv.x, xv.y * wv.y};
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = wave * 8 + i;
+                const float *src = xin + h * 8192 + n * 256 + lane * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const float4 w = winb[(8 * h + pp) * 256 + t];
+                const cf z0 = ldc[256 * (2 * pp) + t];
+                const cf z1 = ldc[256 * (2 * pp + 1) + t];
+                a[safft::brev(16 * h + 2 * pp, 5)] = {z0.x * w.x, z0.y * w.y};
+                a[safft::brev(16 * h + 2 * pp + 1, 5)] = {z1.x * w.z, z1.y * w.w};
+            }
         }
     }
 
@@ -530,7 +546,7 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
         auto kern = chain_f32_kernel<NSEC, OUTK>;                                                      \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_half, tb.win_t, tb.twA, \
+        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.win_t, tb.twA, \
                            tb.twB, tb.twP, tb.lanetab, ka);                                            \
     } while (0)
     switch (out_kind) {

@@ -50,7 +50,8 @@ struct SaQ15Params {
 
 // launchers (defined in chain_f32.hip / chain_q15.hip)
 struct SaF32Tables {
-    const float *win_half;     // [16384] 0.5 * window
+    const float4 *win_b;       // [16][256] 0.5 * window in the pass-A layout of the no-IIR kernel:
+                               //   win_b[p][t] = w[512(2p)+2t], w[..+1], w[512(2p+1)+2t], w[..+1]
     const float4 *win_t;       // [16][256] the same, transposed: win_t[g][t] = win_half[64t + 4g .. +3]
     const float4 *twA;         // [16][256]  (W_8192^(2p*m2), W_8192^((2p+1)*m2))
     const float4 *twB;         // [8][16]    (W_256^(2p*b),   W_256^((2p+1)*b))

@@ -120,7 +120,7 @@ struct sa_handle {
     SaIirK plan_default{}, plan_custom{};
     SaIirLaneTab lt_default{}, lt_custom{};
     // device tables
-    float *d_win_half = nullptr;
+    float4 *d_win_b = nullptr;
     float4 *d_win_t = nullptr;
     float4 *d_twA = nullptr, *d_twB = nullptr;
     float2 *d_twP = nullptr;
@@ -178,8 +178,10 @@ void default_rom(std::vector<int16_t> &rom)
     }
 }
 
-// half = 0.5 * window (exact scaling, undone by the split step).  Two device copies: natural order for
-// the bypass kernel, and transposed (t-major 16-byte units) for the chunk layout of the IIR kernels.
+// half = 0.5 * window (exact scaling, undone by the split step).  Two device copies, each arranged so
+// that the kernel's loads are coalesced 16-byte accesses in the layout it computes in:
+//   tr (IIR kernels, chunk layout):   tr[g][t] = half[64t + 4g .. +3]
+//   pa (no-IIR kernel, pass-A layout): pa[p][t] = half[512(2p)+2t], [..+1], half[512(2p+1)+2t], [..+1]
 void transpose_window(const std::vector<float> &half, std::vector<float> &tr)
 {
     tr.resize(SA_NPTS);
@@ -188,11 +190,25 @@ void transpose_window(const std::vector<float> &half, std::vector<float> &tr)
             for (int e = 0; e < 4; ++e) tr[(g * 256 + t) * 4 + e] = half[64 * t + 4 * g + e];
 }
 
+void pass_a_window(const std::vector<float> &half, std::vector<float> &pa)
+{
+    pa.resize(SA_NPTS);
+    for (int p = 0; p < 16; ++p)
+        for (int t = 0; t < 256; ++t) {
+            float *o = &pa[(p * 256 + t) * 4];
+            o[0] = half[512 * (2 * p) + 2 * t];
+            o[1] = half[512 * (2 * p) + 2 * t + 1];
+            o[2] = half[512 * (2 * p + 1) + 2 * t];
+            o[3] = half[512 * (2 * p + 1) + 2 * t + 1];
+        }
+}
+
 int upload_window_half(sa_handle *h, const std::vector<float> &half)
 {
-    std::vector<float> tr;
+    std::vector<float> tr, pa;
     transpose_window(half, tr);
-    const int rc = upload(h, h->d_win_half, half.data(), sizeof(float) * SA_NPTS);
+    pass_a_window(half, pa);
+    const int rc = upload(h, h->d_win_b, pa.data(), sizeof(float) * SA_NPTS);
     if (rc != SA_OK) return rc;
     return upload(h, h->d_win_t, tr.data(), sizeof(float) * SA_NPTS);
 }
@@ -253,7 +269,7 @@ int sa_create(int device, sa_handle **out)
         }                                                                  \
     } while (0)
     SA_HIPC(hipSetDevice(device));
-    SA_HIPC(hipMalloc(&h->d_win_half, sizeof(float) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_win_b, sizeof(float) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_win_t, sizeof(float) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twA, sizeof(float4) * 16 * 256));
     SA_HIPC(hipMalloc(&h->d_twB, sizeof(float4) * 8 * 16));
@@ -269,9 +285,10 @@ int sa_create(int device, sa_handle **out)
         default_window_f64(w);
         std::vector<float> half(SA_NPTS);
         for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * w[i]);
-        std::vector<float> tr;
+        std::vector<float> tr, pa;
         transpose_window(half, tr);
-        SA_HIPC(hipMemcpy(h->d_win_half, half.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
+        pass_a_window(half, pa);
+        SA_HIPC(hipMemcpy(h->d_win_b, pa.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_win_t, tr.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
         std::vector<float4> ta(16 * 256), tb(8 * 16);
         std::vector<float2> tp(4100);
@@ -329,7 +346,7 @@ int sa_destroy(sa_handle *h)
     if (!h) return SA_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(h->d_win_half);
+    (void)hipFree(h->d_win_b);
     (void)hipFree(h->d_win_t);
     (void)hipFree(h->d_twA);
     (void)hipFree(h->d_twB);
@@ -558,7 +575,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     SA_HIP(h, hipSetDevice(h->device));
     // The section coefficients travel by value in the kernel arguments (stream-ordered by
     // construction); only the small per-lane table lives in device memory.
-    SaF32Tables t = {h->d_win_half, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, nullptr, nullptr};
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, nullptr, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;
