@@ -12,6 +12,7 @@
 //                      (autosort) addressing so the result is in natural order; the arithmetic per
 //                      butterfly is exactly oracle/specan_oracle.c:or_fxfft16k.
 #include "sa_common.hpp"
+#include <type_traits>
 #include "../../include/specan.h"
 
 namespace {
@@ -41,111 +42,169 @@ __device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
 
 // ------------------------------------------------------------------------------------------ IIR
 constexpr int kTile = 256;            // samples per staging tile
-constexpr int kRowPitch = kTile + 2;  // int16 elements; +2 breaks the 8-row bank alignment
+constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
+constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
+constexpr int kRingPitch = kRing + 8;
 constexpr int kFramesPerWave = 8;
 
+// one biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
+// B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum taken
+// modulo 2^16 (wrapping each term first gives the same residue).
+// full-rate 24-bit multiply (samples are 16-bit, taps 8-bit); the compiler otherwise falls back to the
+// quarter-rate v_mul_lo_u32 for some of the products
+__device__ __forceinline__ int mul_i24(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct BiqQ7 {
+    int cB0, cB1, cB2, cA0, cA1;
+    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    __device__ __forceinline__ int step(int x)
+    {
+        const int p0 = mul_i24(x, cB2) >> 7;
+        const int p1 = mul_i24(x1, cB1) >> 7;
+        const int p2 = mul_i24(x2, cB0) >> 7;
+        const int p3 = mul_i24(y2, cA0) >> 7;
+        const int p4 = mul_i24(y1, cA1) >> 7;
+        const int y = (int)(short)(p0 + p1 + p2 - p3 - p4);
+        x2 = x1; x1 = x;
+        y2 = y1; y1 = y;
+        return y;
+    }
+};
+
+// wide mode (build spec, oracle/specan_oracle.c:or_iir_sos_q14): Q2.14 taps, 64-bit accumulator,
+// round-half-up shift by 14, saturation
+struct BiqQ14 {
+    int b0, b1, b2, a1, a2;
+    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    __device__ __forceinline__ int step(int x)
+    {
+        long long acc = (long long)b0 * x + (long long)b1 * x1 + (long long)b2 * x2 - (long long)a1 * y1 -
+                        (long long)a2 * y2;
+        acc = (acc + 8192) >> 14;
+        acc = acc > 32767 ? 32767 : (acc < -32768 ? -32768 : acc);
+        x2 = x1; x1 = x;
+        y2 = y1; y1 = (int)acc;
+        return (int)acc;
+    }
+};
+
+// window + stage one tile of 8 frames x 256 samples into LDS (16 B per lane, two rows per instruction)
+__device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, const int16_t *__restrict__ rom,
+                                               int16_t (*tin)[kRowPitch], int f0, int batch, int n0, int lane,
+                                               int win_mode)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 2 * i + (lane >> 5);
+        const int col = (lane & 31) * 8;
+        const int f = f0 + row;
+        uint4 xv = make_uint4(0, 0, 0, 0);
+        if (f < batch) xv = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
+        const uint4 cv = *reinterpret_cast<const uint4 *>(rom + n0 + col);
+        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int a, b;
+            if (win_mode == SA_WIN_RTL_SIGNED) {
+                a = win_rtl(lo16(xs[k]), lo16(cs[k]));
+                b = win_rtl(hi16(xs[k]), hi16(cs[k]));
+            } else {
+                a = win_u16(lo16(xs[k]), lo16(cs[k]));
+                b = win_u16(hi16(xs[k]), hi16(cs[k]));
+            }
+            *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
+        }
+    }
+}
+
+template <int PITCH>
+__device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const int16_t (*src)[PITCH], int src_col,
+                                               int f0, int batch, int n0, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 2 * i + (lane >> 5);
+        const int col = (lane & 31) * 8;
+        const int f = f0 + row;
+        uint4 ov;
+        ov.x = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 0]);
+        ov.y = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 2]);
+        ov.z = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 4]);
+        ov.w = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 6]);
+        if (f < batch) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
+    }
+}
+
+// One wave = 8 frames x 8 lanes.  Lane `sec` of a frame runs section `sec`; at global step T it works on
+// sample T - sec.  The body is unconditional: before the frame starts every section sees zeros from a
+// zero state (which leaves the state zero), after it ends the extra outputs are simply not stored.
+// The neighbour hand-off is a DPP row shift (a frame's lanes never straddle a 16-lane row); section 0
+// takes its inputs eight at a time from LDS so that no LDS latency sits on the serial chain.
 template <bool WIDE>
 __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restrict__ in,
                                                          int16_t *__restrict__ out, int batch, SaQ15Params prm,
                                                          const int16_t *__restrict__ rom)
 {
-    __shared__ int16_t tin[kFramesPerWave][kRowPitch];
-    __shared__ int16_t tout[kFramesPerWave][kRowPitch];
+    __shared__ __attribute__((aligned(16))) int16_t tin[kFramesPerWave][kRowPitch];
+    __shared__ __attribute__((aligned(16))) int16_t ring[kFramesPerWave][kRingPitch];
     const int lane = threadIdx.x;
     const int fr = lane >> 3;           // frame slot in this wave
     const int sec = lane & 7;           // section index (6,7 idle)
     const int f0 = blockIdx.x * kFramesPerWave;
-    const bool do_iir = prm.filter != SA_FILTER_NONE;
 
-    // per-lane coefficients
-    int cB0 = 0, cB1 = 0, cB2 = 0, cA0 = 0, cA1 = 0;      // q7 (RTL port names)
-    int wb0 = 0, wb1 = 0, wb2 = 0, wa1 = 0, wa2 = 0;      // q14 wide
-    bool active = sec < 6;
-    if constexpr (WIDE) {
-        active = sec < prm.nsec_wide;
-        if (active) {
-            const int16_t *c = &prm.sos_q14[sec * 6];
-            wb0 = c[0]; wb1 = c[1]; wb2 = c[2]; wa1 = c[4]; wa2 = c[5];
+    if (prm.filter == SA_FILTER_NONE) {            // window only
+        for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
+            q15_stage_tile(in, rom, tin, f0, batch, n0, lane, prm.win_mode);
+            __syncthreads();
+            q15_flush_tile<kRowPitch>(out, tin, 0, f0, batch, n0, lane);
+            __syncthreads();
         }
-    } else {
-        const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];
-        cB0 = c[0]; cB1 = c[1]; cB2 = c[2]; cA0 = c[3]; cA1 = c[4];
+        return;
     }
-    const int last_sec = WIDE ? (prm.nsec_wide - 1) : 5;
-    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;                   // section state, zero at frame start
 
-    for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
-        // ---- stage in: 8 rows x 256 samples, 16 B per lane, window applied on the way
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 2 * i + (lane >> 5);
-            const int col = (lane & 31) * 8;
-            const int f = f0 + row;
-            uint4 xv = make_uint4(0, 0, 0, 0);
-            if (f < batch) xv = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
-            const uint4 cv = *reinterpret_cast<const uint4 *>(rom + n0 + col);
-            const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int a, b;
-                if (prm.win_mode == SA_WIN_RTL_SIGNED) {
-                    a = win_rtl(lo16(xs[k]), lo16(cs[k]));
-                    b = win_rtl(hi16(xs[k]), hi16(cs[k]));
-                } else {
-                    a = win_u16(lo16(xs[k]), lo16(cs[k]));
-                    b = win_u16(hi16(xs[k]), hi16(cs[k]));
-                }
-                *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
-            }
-        }
+    using Biq = typename std::conditional<WIDE, BiqQ14, BiqQ7>::type;
+    Biq bq{};
+    int last_sec = 5;
+    if constexpr (WIDE) {
+        last_sec = prm.nsec_wide - 1;
+        if (sec < prm.nsec_wide) {
+            const int16_t *c = &prm.sos_q14[sec * 6];
+            bq.b0 = c[0]; bq.b1 = c[1]; bq.b2 = c[2]; bq.a1 = c[4]; bq.a2 = c[5];
+        }                                   // idle lanes keep all-zero taps: output 0
+    } else {
+        const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
+        bq.cB0 = c[0]; bq.cB1 = c[1]; bq.cB2 = c[2]; bq.cA0 = c[3]; bq.cA1 = c[4];
+    }
+    const bool is_first = sec == 0, is_last = sec == last_sec;
+    int yprev = 0;
+
+    for (int k = 0; k <= SA_NPTS / kTile; ++k) {   // one extra block drains the pipeline
+        const bool live = k < SA_NPTS / kTile;
+        if (live) q15_stage_tile(in, rom, tin, f0, batch, k * kTile, lane, prm.win_mode);
         __syncthreads();
-        if (do_iir) {
-            // ---- systolic run over the tile: step tau, lane `sec` handles local sample tau - sec
-            int yprev = 0;     // this lane's output of the previous step
-            for (int tau = 0; tau < kTile + 7; ++tau) {
-                const int up = __shfl_up(yprev, 1, 64);          // neighbour section's last output
-                const int i = tau - sec;
-                int x = up;
-                if (sec == 0 && i < kTile) x = tin[fr][i < 0 ? 0 : i];
-                int y = 0;
-                if (active && i >= 0 && i < kTile) {
-                    if constexpr (WIDE) {
-                        long long acc = (long long)wb0 * x + (long long)wb1 * x1 + (long long)wb2 * x2 -
-                                        (long long)wa1 * y1 - (long long)wa2 * y2;
-                        acc = (acc + 8192) >> 14;
-                        acc = acc > 32767 ? 32767 : (acc < -32768 ? -32768 : acc);
-                        y = (int)acc;
-                    } else {
-                        // B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7,
-                        // sum taken modulo 2^16 (wrapping each term first gives the same residue)
-                        const int acc = ((x * cB2) >> 7) + ((x1 * cB1) >> 7) + ((x2 * cB0) >> 7) -
-                                        ((y2 * cA0) >> 7) - ((y1 * cA1) >> 7);
-                        y = (int)(short)acc;
-                    }
-                    x2 = x1; x1 = x;
-                    y2 = y1; y1 = y;
-                    if (sec == last_sec) tout[fr][i] = (int16_t)y;
-                }
+        const int nsteps = live ? kTile / 8 : 1;
+        for (int g = 0; g < nsteps; ++g) {
+            uint4 pk = make_uint4(0, 0, 0, 0);
+            if (live) pk = *reinterpret_cast<const uint4 *>(&tin[fr][8 * g]);
+            const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int T = k * kTile + 8 * g + e;
+                const int xin = (e & 1) ? hi16(w[e >> 1]) : lo16(w[e >> 1]);
+                const int up = __builtin_amdgcn_update_dpp(0, yprev, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+                const int y = bq.step(is_first ? xin : up);
                 yprev = y;
+                if (is_last) ring[fr][(T - last_sec) & (kRing - 1)] = (int16_t)y;
             }
         }
         __syncthreads();
-        // ---- stage out
-        int16_t (*src)[kRowPitch] = do_iir ? tout : tin;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 2 * i + (lane >> 5);
-            const int col = (lane & 31) * 8;
-            const int f = f0 + row;
-            uint4 ov;
-            ov.x = *reinterpret_cast<unsigned *>(&src[row][col + 0]);
-            ov.y = *reinterpret_cast<unsigned *>(&src[row][col + 2]);
-            ov.z = *reinterpret_cast<unsigned *>(&src[row][col + 4]);
-            ov.w = *reinterpret_cast<unsigned *>(&src[row][col + 6]);
-            if (f < batch) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
-        }
-        __syncthreads();
+        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
     }
 }
 
