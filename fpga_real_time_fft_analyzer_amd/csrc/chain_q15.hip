@@ -45,31 +45,32 @@ constexpr int kTile = 256;            // samples per staging tile
 constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
-constexpr int kFramesPerWave = 8;
+constexpr int kFramesPerWave = 4;      // one frame per 16-lane row: lane 0..5 of the row = section 0..5
 
-// one biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
-// B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum taken
-// modulo 2^16 (wrapping each term first gives the same residue).
-// full-rate 24-bit multiply (samples are 16-bit, taps 8-bit); the compiler otherwise falls back to the
-// quarter-rate v_mul_lo_u32 for some of the products
-__device__ __forceinline__ int mul_i24(int a, int b)
+// full-rate 24-bit multiply-add (samples are 16-bit, taps 8-bit); the compiler otherwise falls back to
+// the quarter-rate v_mul_lo_u32 for some of the products
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
 {
     int r;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
+// one biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
+//   y = B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum
+//   taken modulo 2^16 (wrapping each term first gives the same residue).
+// The two subtracted terms use -floor(v/128) = floor((-v + 127)/128), so all five terms add.
 struct BiqQ7 {
-    int cB0, cB1, cB2, cA0, cA1;
+    int cB0, cB1, cB2, nA0, nA1;            // nA* = -A*
     int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
     __device__ __forceinline__ int step(int x)
     {
-        const int p0 = mul_i24(x, cB2) >> 7;
-        const int p1 = mul_i24(x1, cB1) >> 7;
-        const int p2 = mul_i24(x2, cB0) >> 7;
-        const int p3 = mul_i24(y2, cA0) >> 7;
-        const int p4 = mul_i24(y1, cA1) >> 7;
-        const int y = (int)(short)(p0 + p1 + p2 - p3 - p4);
+        const int p1 = mad_i24(x1, cB1, 0) >> 7;
+        const int p2 = mad_i24(x2, cB0, 0) >> 7;
+        const int p3 = mad_i24(y2, nA0, 127) >> 7;
+        const int p4 = mad_i24(y1, nA1, 127) >> 7;
+        const int p0 = mad_i24(x, cB2, 0) >> 7;
+        const int y = (int)(short)((p1 + p2 + p3) + (p4 + p0));
         x2 = x1; x1 = x;
         y2 = y1; y1 = y;
         return y;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, c
                                                int win_mode)
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kFramesPerWave / 2; ++i) {
         const int row = 2 * i + (lane >> 5);
         const int col = (lane & 31) * 8;
         const int f = f0 + row;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
                                                int f0, int batch, int n0, int lane)
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kFramesPerWave / 2; ++i) {
         const int row = 2 * i + (lane >> 5);
         const int col = (lane & 31) * 8;
         const int f = f0 + row;
@@ -141,11 +142,13 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
     }
 }
 
-// One wave = 8 frames x 8 lanes.  Lane `sec` of a frame runs section `sec`; at global step T it works on
-// sample T - sec.  The body is unconditional: before the frame starts every section sees zeros from a
-// zero state (which leaves the state zero), after it ends the extra outputs are simply not stored.
-// The neighbour hand-off is a DPP row shift (a frame's lanes never straddle a 16-lane row); section 0
-// takes its inputs eight at a time from LDS so that no LDS latency sits on the serial chain.
+// One wave = 4 frames, one per 16-lane row.  Lane `sec` of a row runs section `sec`; at global step T it
+// works on sample T - sec.  The body is unconditional: before the frame starts every section sees zeros
+// from a zero state (which leaves the state zero), after it ends the extra outputs are not stored.
+// The neighbour hand-off is a DPP row shift whose out-of-row case (lane 0 = section 0) keeps the `old`
+// operand, which holds the next input sample: no select.  Section 0 takes its inputs eight at a time
+// from LDS, so no LDS latency sits on the serial chain.  With 4096 frames that is 1024 waves, one per
+// SIMD of the chip; the chain is serial in time, so lanes, not waves, are what is left idle.
 template <bool WIDE>
 __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restrict__ in,
                                                          int16_t *__restrict__ out, int batch, SaQ15Params prm,
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
 {
     __shared__ __attribute__((aligned(16))) int16_t tin[kFramesPerWave][kRowPitch];
     __shared__ __attribute__((aligned(16))) int16_t ring[kFramesPerWave][kRingPitch];
+    __shared__ int16_t trash[64];
     const int lane = threadIdx.x;
-    const int fr = lane >> 3;           // frame slot in this wave
-    const int sec = lane & 7;           // section index (6,7 idle)
+    const int fr = lane >> 4;           // frame slot in this wave
+    const int sec = lane & 15;          // section index (6..15 idle)
     const int f0 = blockIdx.x * kFramesPerWave;
 
     if (prm.filter == SA_FILTER_NONE) {            // window only
@@ -178,10 +182,17 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
             bq.b0 = c[0]; bq.b1 = c[1]; bq.b2 = c[2]; bq.a1 = c[4]; bq.a2 = c[5];
         }                                   // idle lanes keep all-zero taps: output 0
     } else {
-        const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
-        bq.cB0 = c[0]; bq.cB1 = c[1]; bq.cB2 = c[2]; bq.cA0 = c[3]; bq.cA1 = c[4];
+        if (sec < 6) {
+            const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
+            bq.cB0 = c[0]; bq.cB1 = c[1]; bq.cB2 = c[2]; bq.nA0 = -(int)c[3]; bq.nA1 = -(int)c[4];
+        } else {
+            bq.cB0 = bq.cB1 = bq.cB2 = bq.nA0 = bq.nA1 = 0;
+        }
     }
-    const bool is_first = sec == 0, is_last = sec == last_sec;
+    // only the last section's lane stores; the others write to a private trash slot (stride 0)
+    const bool is_last = sec == last_sec;
+    int16_t *wbase = is_last ? &ring[fr][0] : &trash[lane];
+    const int wstride = is_last ? 1 : 0;
     int yprev = 0;
 
     for (int k = 0; k <= SA_NPTS / kTile; ++k) {   // one extra block drains the pipeline
@@ -197,10 +208,11 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
             for (int e = 0; e < 8; ++e) {
                 const int T = k * kTile + 8 * g + e;
                 const int xin = (e & 1) ? hi16(w[e >> 1]) : lo16(w[e >> 1]);
-                const int up = __builtin_amdgcn_update_dpp(0, yprev, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
-                const int y = bq.step(is_first ? xin : up);
+                // lane 0 of the row has no left neighbour: bound_ctrl = false keeps `old` = xin there
+                const int x = __builtin_amdgcn_update_dpp(xin, yprev, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+                const int y = bq.step(x);
                 yprev = y;
-                if (is_last) ring[fr][(T - last_sec) & (kRing - 1)] = (int16_t)y;
+                wbase[((T - last_sec) & (kRing - 1)) * wstride] = (int16_t)y;
             }
         }
         __syncthreads();
