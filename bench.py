@@ -126,11 +126,9 @@ def main():
         ch.process_f32(x, out=out)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    elapsed = t1 - t0
+    from bench_shard import aggregate_fps
+    fps_total, elapsed = aggregate_fps(B, a.steps, t1 - t0, world)     # MAX over ranks (gloo, host side)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
         dist.barrier()
 
     # per-launch kernel time with HIP events on the launch stream (torch's current stream is the one
@@ -172,11 +170,10 @@ def main():
             extras[name] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
 
     if rank == 0:
-        frames = B * world * a.steps
         achieved = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
         line = {
             "metric": "16K-pt frames/sec (window+IIR+FFT), batch=4096",
-            "value": round(frames / elapsed, 1),
+            "value": round(fps_total, 1),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": a.steps,

@@ -167,3 +167,44 @@ def test_full_size_batch(ch, torch_mod, oracle):
     perm = torch.randperm(B, generator=gen, device="cuda")
     iq2 = ch.process_q15(x[perm].contiguous())
     assert torch.equal(iq2, iq[perm])
+
+
+def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
+    """N1/N2: the board as gui.py sees it -- command bytes in, frames / datagrams out."""
+    from fpga_real_time_fft_analyzer_amd import designer, frames
+    from fpga_real_time_fft_analyzer_amd.virtual_fpga import VirtualFpga
+    rng = np.random.default_rng(8)
+    src_frames = rng.integers(-2048, 2048, size=(6, N)).astype(np.int16)
+    served = []
+
+    def source(n):
+        i = len(served)
+        served.extend(range(i, i + n))
+        return src_frames[[j % 6 for j in range(i, i + n)]]
+
+    fpga = VirtualFpga(source, device=0, batch=3)
+    q = designer.two_sections_for_fpga(designer.quantize_coefficients(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0)))
+    fpga.write(designer.coefficient_upload_bytes(q) + bytes([0xA1, 0x55]))     # upload, select custom, start
+    assert fpga.read() != b"" or True
+    fpga.read()
+    fpga.write(bytes([0xA5]))                                                 # UART frame request (gui.py:28)
+    f1 = fpga.read()
+    assert len(f1) == 65536
+    ref = oracle.chain_q15(src_frames[1:2], None, 0, 0xA1, np.array(q, np.int8).reshape(12), None)
+    assert f1 == ref[0].astype("<i2").tobytes()                               # second frame: 0x55 took the first
+    # coefficient bytes equal to 0xA5 must not trigger frames
+    fpga.write(bytes([0xF1] + [0xA5] * 12))
+    assert fpga.read() == b""
+    # Ethernet mode: 64 datagrams reassemble to the frame
+    fpga.write(bytes([0xEF, 0xB1, 0xA5]))
+    dg = fpga.read_datagrams()
+    assert len(dg) == 64 and all(len(d) == 1025 for d in dg)
+    asm = frames.FrameAssembler()
+    got = None
+    for d in dg:
+        got = asm.add(d, 0)
+    assert got is not None and len(got) == 65536
+    assert len(list(fpga.stream(4))) == 4
+    fpga.write(bytes([0xFF]))                                                 # reset
+    assert fpga.chain.filter_mode == 0xB1 and not fpga.started
+    fpga.close()
