@@ -170,6 +170,16 @@ def main():
             extras[name] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
 
     if rank == 0:
+        # HBM traffic per launch from the committed PMC passes of this same kernel and batch (counters
+        # cannot be read inside the timed process); null when the profile is for another batch size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                pj = json.load(fh)
+            if pj.get("batch") == B:
+                traffic = pj["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         achieved = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
         line = {
             "metric": "16K-pt frames/sec (window+IIR+FFT), batch=4096",
@@ -188,7 +198,7 @@ def main():
                                    f"wn=0.2) + 16K FFT + magnitude, all 16384 bins written (BASELINE.json configs[2])",
                        "frames_per_gpu": B, "sharding": "batch, independent per-GPU streams, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "chain_f32_kernel<IIR,MAG_FULL>", "kernel_ms_avg": round(k_avg_ms, 4),
                          "kernel_ms_median": round(k_med_ms, 4),
                          "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32},

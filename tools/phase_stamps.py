@@ -19,9 +19,11 @@ from fpga_real_time_fft_analyzer_amd import abi  # noqa: E402
 abi.LIB_PATH = os.path.join(ROOT, "fpga_real_time_fft_analyzer_amd", "libspecan_hip_stamps.so")
 from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
 
-NAMES = ["stage-in (global->LDS->chunk)", "IIR cascade", "exchange to pass A", "FFT32 + twiddle A",
-         "(wait) ", "exchange A->B", "read B", "FFT16x2 + twiddle B", "exchange B->C", "FFT16x2",
-         "exchange to natural", "split + stores issued", "store drain"]
+NAMES = {"0->1": "stage-in (DMA + chunk read x window)", "1->2": "IIR cascade (6 sections)",
+         "2->3": "exchange to pass A", "0->3": "stage-in (DMA + read x window)", "3->4": "FFT32 + twiddle A",
+         "4->5": "exchange A->B (2 rounds)", "5->6": "FFT16x2 + twiddle B", "6->7": "exchange B->C (in-row)",
+         "7->8": "FFT16x2", "8->9": "natural image round 0", "9->10": "split+store round 0, image round 1",
+         "10->11": "split+store round 1", "11->12": "store drain"}
 
 
 def main():
@@ -47,7 +49,7 @@ def main():
     print(f"B={B} mode=0x{mode:02X}: workgroup lifetime median {np.median(tot):.0f} clk (s_memtime ticks = 100 MHz? see note)")
     labels = [f"{idx[i]}->{idx[i+1]}" for i in range(len(idx) - 1)]
     for i, lab in enumerate(labels):
-        print(f"  {lab:7s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}"
+        print(f"  {lab:7s} {NAMES.get(lab, ''):42s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}"
               f"  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
     span = s[:, 12].max() - s[:, 0].min()
     print(f"  whole grid span {span:.0f} clk; sum of WG lifetimes / span = {tot.sum() / span:.1f} resident WGs on average")
