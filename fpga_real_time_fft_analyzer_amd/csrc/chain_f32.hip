@@ -53,6 +53,16 @@ __device__ unsigned long long *g_sa_stamps = nullptr;
 #define SA_STAMP(i) do {} while (0)
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. it waits for every outstanding global load AND store of the wave;
+// the exchanges below hand data over through LDS alone, so in-flight twiddle loads and output stores
+// may stay in flight across them.  (The stage-in barrier keeps __syncthreads(): the LDS-DMA completes
+// on vmcnt.)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // DPP helpers: value of the lane `n` to the left inside the 16-lane row, 0 when there is none.
 template <int N>
@@ -143,7 +153,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     const int row = 4 * wave + (lane >> 4);
     if ((lane & 15) == 15) scr_s[row] = make_float2(t1, t2);
     const float e1 = row_shr<1>(t1), e2 = row_shr<1>(t2);       // exclusive: state before this thread, row-local
-    __syncthreads();
+    lds_barrier();
     // scan over the 16 row totals (every row of every wave repeats it: 16 lanes, 4 DPP levels)
     const float2 tt = scr_s[lane & 15];
     float r1 = tt.x, r2 = tt.y;
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
         float *ldim = ldre + 128 * 33;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            __syncthreads();
+            lds_barrier();
             if ((t >> 7) == h) {
                 const int base = 33 * (t & 127);
 #pragma unroll
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
                     ldim[base + 16 + j] = d[2 * j + 1].y;
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const int pos = 264 * m + 33 * (t >> 5) + (t & 31);
@@ -395,10 +405,10 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     cf p[2][16];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        __syncthreads();                                   // previous image fully consumed
+        lds_barrier();                                   // previous image fully consumed
 #pragma unroll
         for (int r = 0; r < 16; ++r) ldc[r * 272 + t] = a[16 * q + r];
-        __syncthreads();
+        lds_barrier();
         const int row = 4 * wave + kq;
 #pragma unroll
         for (int aa = 0; aa < 16; ++aa) p[q][safft::brev(aa, 4)] = ldc[row * 272 + 16 * aa + lo];
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     //      travel through two side slots.
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k1 = 16 * q + 4 * wave + kq;
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
             side[0] = p[0][12];
             side[1] = p[0][4];
         }
-        __syncthreads();
+        lds_barrier();
         SA_STAMP(9 + r);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -517,11 +527,20 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     }
 }
 
+// Raise the dynamic-LDS limit once per kernel and device (not a stream operation: doing it on every
+// launch costs host time and is not capturable into a hipGraph).
 template <typename K>
 hipError_t set_lds(K kernel)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kLdsBytes);
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsBytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    return e;
 }
 
 }  // namespace

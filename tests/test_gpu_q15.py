@@ -208,3 +208,18 @@ def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
     fpga.write(bytes([0xFF]))                                                 # reset
     assert fpga.chain.filter_mode == 0xB1 and not fpga.started
     fpga.close()
+
+
+def test_ingest_double_buffer_feeds_the_chain(ch, torch_mod, oracle):
+    """N3: framed host samples -> pinned double buffer -> device -> path, bit-exact per batch."""
+    from fpga_real_time_fft_analyzer_amd.ingest import DeviceFeeder, FrameCutter
+    rng = np.random.default_rng(12)
+    stream = rng.integers(-2048, 2048, size=5 * N + 100).astype(np.int16)
+    fc = FrameCutter()
+    batches = [fc.push(stream[:2 * N + 7]), fc.push(stream[2 * N + 7:4 * N]), fc.push(stream[4 * N:])]
+    batches = [b for b in batches if b.shape[0]]
+    assert sum(b.shape[0] for b in batches) == 5
+    feeder = DeviceFeeder(0, max_batch=8)
+    outs = [ch.process_q15(xd).cpu().numpy() for xd in feeder.feed(batches)]
+    ref = oracle.chain_q15(stream[:5 * N].reshape(5, N))
+    assert np.array_equal(np.concatenate(outs), ref)

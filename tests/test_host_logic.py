@@ -189,3 +189,40 @@ def test_iir_plan_rejects_bad_sos(hip_lib_built):
     with pytest.raises(SpecanError):
         iir_plan_from_sos(np.array([[1, 0, 0, 0, 0, 0.0]]))     # a0 = 0
     assert int(iir_plan_from_sos(np.zeros((0, 6)))[:1].view(np.int32)[0]) == 0
+
+
+# ---- N2 / N3 edges: framing front-end and UDP emitter (pure host logic)
+def test_frame_cutter():
+    from fpga_real_time_fft_analyzer_amd.ingest import FrameCutter
+    fc = FrameCutter()
+    x = np.arange(40000, dtype=np.int32) % 4096 - 2048
+    out = fc.push(x[:10000])
+    assert out.shape == (0, N) and fc.pending == 10000
+    out = fc.push(x[10000:])
+    assert out.shape == (2, N) and fc.pending == 40000 - 2 * N
+    assert np.array_equal(out[0], x[:N]) and np.array_equal(out[1], x[N:2 * N])
+    fo = FrameCutter(hop=N // 2)
+    out = fo.push(x[:2 * N])
+    assert out.shape == (3, N) and np.array_equal(out[1], x[N // 2:N // 2 + N]) and fo.pending == N // 2
+    with pytest.raises(ValueError):
+        FrameCutter(hop=0)
+    with pytest.raises(ValueError):
+        FrameCutter().push(np.array([40000]))
+
+
+def test_udp_emit_loopback():
+    import socket
+    from fpga_real_time_fft_analyzer_amd.ingest import udp_emit
+    g = load_golden("g6_frame.npz")
+    frame = g["frame"].tobytes()
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 20)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(5.0)
+    assert udp_emit(frame, rx.getsockname()) == 64
+    asm = frames.FrameAssembler()
+    got = None
+    for _ in range(64):
+        got = asm.add(rx.recv(2048), 0)
+    rx.close()
+    assert got == frame
