@@ -138,7 +138,7 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 // One cascade section, in place on the thread's two chunks.
 //   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
 //   z1,z2 (out): the same for the NEXT section (accumulated while this section's outputs appear)
-template <bool PREDICT_NEXT>
+template <bool PREDICT_NEXT, bool UNIT>
 __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float4 *mt_next,
                                             const float4 lanep, float2 *scr_s, int lane, int wave, v2f &z1, v2f &z2)
 {
@@ -179,9 +179,16 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const v2f x = d[j];
-        const v2f y = b0 * x + s1;
-        s1 = na1 * y + (b1 * x + s2);
-        s2 = na2 * y + b2 * x;
+        v2f y;
+        if constexpr (UNIT) {                 // b = [1, r1, 1]: the cascade gain sits in the window table
+            y = x + s1;
+            s1 = na1 * y + (b1 * x + s2);
+            s2 = na2 * y + x;
+        } else {
+            y = b0 * x + s1;
+            s1 = na1 * y + (b1 * x + s2);
+            s2 = na2 * y + b2 * x;
+        }
         d[j] = y;
         if constexpr (PREDICT_NEXT) {
             const float4 mm = mt_next[j];                     // wave-uniform LDS broadcast (m1,m1,m2,m2)
@@ -197,22 +204,22 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
 // All NSEC sections run unconditionally (the host pads shorter cascades with identity sections,
 // which are exact: y = 1*x + 0).  A run-time section count would carry the 64 data registers
 // through control-flow merges and cost ~190 register copies.
-template <int S, int NSEC>
+template <int S, int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                              const float4 *mtab, float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
 {
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
         if constexpr (S + 1 < NSEC)
-            iir_section<true>(d, ka.sec[S], mtab + 32 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
+            iir_section<true, UNIT>(d, ka.sec[S], mtab + 32 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
         else
-            iir_section<false>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
-        iir_sections<S + 1, NSEC>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
+            iir_section<false, UNIT>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
+        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
     }
 }
 
 // mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][32] float4 = (m1[j],m1[j],m2[j],m2[j])
-template <int NSEC>
+template <int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                             const float4 *mtab, float2 *scr, int t)
 {
@@ -225,7 +232,7 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, cons
         z1 = safft::pk_fma(m1, d[j], z1);
         z2 = safft::pk_fma(m2, d[j], z2);
     }
-    iir_sections<0, NSEC>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
+    iir_sections<0, NSEC, UNIT>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
 }
 
 // copy the predictor taps into LDS as (m1,m1,m2,m2) per tap (first 192 threads, one tap each); visible
@@ -300,11 +307,10 @@ __device__ __forceinline__ int zpos(int k, int round)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NSEC, int OUT>
+template <int NSEC, bool UNIT, int OUT>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
-                                                                 const float4 *__restrict__ wint,
                                                                  const float4 *__restrict__ twA,
                                                                  const float4 *__restrict__ twB,
                                                                  const float2 *__restrict__ twP,
@@ -333,9 +339,9 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
         v2f d[32];
         float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
         load_mtab(lanetab, mtab, t);
-        stage_in_chunks(xin, wint, smem, t, d);
+        stage_in_chunks(xin, reinterpret_cast<const float4 *>(lanetab->win_t), smem, t, d);
         SA_STAMP(1);
-        iir_cascade<NSEC>(d, ka, lanetab, mtab, scr, t);
+        iir_cascade<NSEC, UNIT>(d, ka, lanetab, mtab, scr, t);
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
         // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
@@ -502,10 +508,10 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
-template <int NSEC>
+template <int NSEC, bool UNIT>
 __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__restrict__ in,
                                                                 float *__restrict__ out, int batch,
-                                                                const float4 *__restrict__ wint,
+                                                                const float4 *__restrict__ wint_plain,
                                                                 const SaIirLaneTab *__restrict__ lanetab,
                                                                 const SaIirK ka)
 {
@@ -517,8 +523,9 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     v2f d[32];
     float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
     if constexpr (NSEC > 0) load_mtab(lanetab, mtab, t);
+    const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
     stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
-    if constexpr (NSEC > 0) iir_cascade<NSEC>(d, ka, lanetab, mtab, scr, t);
+    if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, mtab, scr, t);
     float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)
@@ -554,7 +561,7 @@ extern "C" int sa_debug_set_stamps(void *p)
 
 namespace {
 
-template <int NSEC>
+template <int NSEC, bool UNIT>
 hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK &ka,
                        hipStream_t stream)
 {
@@ -562,10 +569,10 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
     hipError_t e = hipSuccess;
 #define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
-        auto kern = chain_f32_kernel<NSEC, OUTK>;                                                      \
+        auto kern = chain_f32_kernel<NSEC, UNIT, OUTK>;                                                \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.win_t, tb.twA, \
+        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twA, \
                            tb.twB, tb.twP, tb.lanetab, ka);                                            \
     } while (0)
     switch (out_kind) {
@@ -573,7 +580,7 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
         case SA_OUT_MAG_HALF: SA_LAUNCH(SA_OUT_MAG_HALF); break;
         case SA_OUT_SPEC_HALF: SA_LAUNCH(SA_OUT_SPEC_HALF); break;
         case SA_OUT_TIME: {
-            auto kern = time_f32_kernel<NSEC>;
+            auto kern = time_f32_kernel<NSEC, UNIT>;
             e = set_lds(kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, reinterpret_cast<float *>(out), batch,
@@ -596,11 +603,15 @@ hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_ki
     static const SaIirK kNoIir = {};
     const int nsec = tb.iir ? tb.iir->nsec : 0;
     const SaIirK &ka = nsec > 0 ? *tb.iir : kNoIir;
+    const bool unit = nsec > 0 && ka.unit != 0;
     switch (nsec) {
-        case 0: return launch_nsec<0>(in, out, batch, out_kind, tb, ka, stream);
-        case 2: return launch_nsec<2>(in, out, batch, out_kind, tb, ka, stream);
-        case 4: return launch_nsec<4>(in, out, batch, out_kind, tb, ka, stream);
-        case 6: return launch_nsec<6>(in, out, batch, out_kind, tb, ka, stream);
+        case 0: return launch_nsec<0, false>(in, out, batch, out_kind, tb, ka, stream);
+        case 2: return unit ? launch_nsec<2, true>(in, out, batch, out_kind, tb, ka, stream)
+                            : launch_nsec<2, false>(in, out, batch, out_kind, tb, ka, stream);
+        case 4: return unit ? launch_nsec<4, true>(in, out, batch, out_kind, tb, ka, stream)
+                            : launch_nsec<4, false>(in, out, batch, out_kind, tb, ka, stream);
+        case 6: return unit ? launch_nsec<6, true>(in, out, batch, out_kind, tb, ka, stream)
+                            : launch_nsec<6, false>(in, out, batch, out_kind, tb, ka, stream);
         default: return hipErrorInvalidValue;
     }
 }

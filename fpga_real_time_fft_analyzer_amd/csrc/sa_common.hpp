@@ -23,8 +23,11 @@ struct SaIirSecK {
 };
 
 struct SaIirK {
-    int nsec;
-    int pad[3];
+    int nsec;              // padded section count the kernel is compiled for: 0, 2, 4 or 6
+    int unit;              // 1: every section is in unit-numerator form b = [1, r1, 1] (cascade gain folded
+                           //    into the window table of this plan); the recursion then needs 4 ops, not 5
+    float gain;            // the folded cascade gain (1 when unit == 0); informational for tests
+    int pad;
     SaIirSecK sec[SA_MAXSEC];
 };
 
@@ -32,9 +35,12 @@ struct SaIirK {
 //   m[s][j]   = predictor taps (m1, m2): chunk end state from zero state = sum_j m[s][j] x[j];
 //               copied into LDS at kernel start and read as wave-uniform broadcasts
 //   p[s][i]   = P2^i, i = lane index inside its 16-lane row (start-state injection per lane)
+//   win_t     = 0.5 * window * G, transposed for the chunk layout (win_t[g][t][e] = w[64t + 4g + e]);
+//               G = product of the sections' b0 when the plan is in unit-numerator form, else 1
 struct SaIirLaneTab {
     float m[SA_MAXSEC][SA_CHUNK][2];
     float p[SA_MAXSEC][16][4];
+    float win_t[SA_NPTS];
 };
 
 // Integer-path parameters passed by value (kernarg => stream-ordered for free).

@@ -48,7 +48,13 @@ inline void put(float *dst, const Mat2 &m)
 // Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
 // The kernels are compiled for 2, 4 and 6 sections; shorter cascades are padded with identity
 // sections (b0 = 1, rest 0: y = x exactly, all scan matrices and predictor taps come out zero).
-void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *lt)
+//
+// Unit-numerator form: when no padding is needed and every section has b2 == b0 != 0 (all-pole-pair
+// zeros on the unit circle: Butterworth / Chebyshev / elliptic low-, high-pass and band-stop), the
+// sections are rewritten as b = [1, b1/b0, 1] and the product of the b0's is folded into this plan's
+// copy of the window: one multiply less per sample and section in the recursion.
+// half_win: 0.5 * window in natural order (size SA_NPTS).
+void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *lt, const float *half_win)
 {
     std::memset(plan, 0, sizeof(*plan));
     std::memset(lt, 0, sizeof(*lt));
@@ -57,7 +63,32 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
     for (int s = 0; s < nsec; ++s)
         for (int i = 0; i < 6; ++i)
             sos[6 * s + i] = s < nsec_in ? sos_in[6 * s + i] : ((i == 0 || i == 3) ? 1.0 : 0.0);
+    bool unit = nsec > 0 && nsec == nsec_in;
+    double gain = 1.0;
+    for (int s = 0; s < nsec && unit; ++s) {
+        const double b0 = sos[6 * s], b2 = sos[6 * s + 2];
+        if (b0 == 0.0 || b2 != b0 || !std::isfinite(1.0 / b0)) unit = false;
+        gain *= b0;
+    }
+    if (unit && (!std::isfinite(gain) || std::fabs(gain) < 1e-30 || std::fabs(gain) > 1e30)) unit = false;
+    if (unit) {
+        for (int s = 0; s < nsec; ++s) {
+            const double b0 = sos[6 * s];
+            sos[6 * s + 1] /= b0;
+            sos[6 * s] = 1.0;
+            sos[6 * s + 2] = 1.0;
+        }
+    } else {
+        gain = 1.0;
+    }
     plan->nsec = nsec;
+    plan->unit = unit ? 1 : 0;
+    plan->gain = (float)gain;
+    if (half_win)
+        for (int t = 0; t < 256; ++t)
+            for (int g = 0; g < 16; ++g)
+                for (int e = 0; e < 4; ++e)
+                    lt->win_t[(g * 256 + t) * 4 + e] = (float)((double)half_win[64 * t + 4 * g + e] * gain);
     for (int s = 0; s < nsec; ++s) {
         const double *r = sos + 6 * s;
         const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
@@ -119,6 +150,9 @@ struct sa_handle {
     std::vector<int16_t> rom;
     SaIirK plan_default{}, plan_custom{};
     SaIirLaneTab lt_default{}, lt_custom{};
+    std::vector<float> half_win;           // 0.5 * float window, natural order
+    double sos_custom[36] = {0};          // a0-normalised custom cascade (kept to rebuild on window change)
+    int nsec_custom = 0;
     // device tables
     float4 *d_win_b = nullptr;
     float4 *d_win_t = nullptr;
@@ -203,14 +237,19 @@ void pass_a_window(const std::vector<float> &half, std::vector<float> &pa)
         }
 }
 
+int rebuild_plans(sa_handle *h);
+
 int upload_window_half(sa_handle *h, const std::vector<float> &half)
 {
     std::vector<float> tr, pa;
     transpose_window(half, tr);
     pass_a_window(half, pa);
-    const int rc = upload(h, h->d_win_b, pa.data(), sizeof(float) * SA_NPTS);
+    h->half_win = half;
+    int rc = upload(h, h->d_win_b, pa.data(), sizeof(float) * SA_NPTS);
     if (rc != SA_OK) return rc;
-    return upload(h, h->d_win_t, tr.data(), sizeof(float) * SA_NPTS);
+    rc = upload(h, h->d_win_t, tr.data(), sizeof(float) * SA_NPTS);
+    if (rc != SA_OK) return rc;
+    return rebuild_plans(h);          // each plan carries its own (gain-scaled) copy of the window
 }
 
 int set_window_f32_from(sa_handle *h, const float *w)
@@ -223,11 +262,13 @@ int set_window_f32_from(sa_handle *h, const float *w)
 // flat float view for tests: SaIirK followed by SaIirLaneTab
 int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
 {
-    const int n1 = (int)(sizeof(SaIirK) / sizeof(float)), n2 = (int)(sizeof(SaIirLaneTab) / sizeof(float));
+    // the flat view stops before the per-plan window copy (tests read the taps and matrices only)
+    const int n1 = (int)(sizeof(SaIirK) / sizeof(float));
+    const int n2 = (int)((sizeof(lt.m) + sizeof(lt.p)) / sizeof(float));
     if (out && cap > 0) {
         std::vector<float> tmp(n1 + n2);
         std::memcpy(tmp.data(), &p, sizeof(SaIirK));
-        std::memcpy(tmp.data() + n1, &lt, sizeof(SaIirLaneTab));
+        std::memcpy(tmp.data() + n1, &lt, sizeof(float) * (size_t)n2);
         std::memcpy(out, tmp.data(), sizeof(float) * (size_t)(cap < n1 + n2 ? cap : n1 + n2));
     }
     return n1 + n2;
@@ -235,7 +276,21 @@ int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
 
 int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
 {
-    build_plan(sos_norm, nsec, &h->plan_custom, &h->lt_custom);
+    std::memset(h->sos_custom, 0, sizeof h->sos_custom);
+    std::memcpy(h->sos_custom, sos_norm, sizeof(double) * 6 * (size_t)nsec);
+    h->nsec_custom = nsec;
+    build_plan(h->sos_custom, nsec, &h->plan_custom, &h->lt_custom, h->half_win.data());
+    return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
+}
+
+int rebuild_plans(sa_handle *h)
+{
+    double sos[36];
+    sos_from_q7(kDefaultQ7, sos);
+    build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data());
+    int rc = upload(h, h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab));
+    if (rc != SA_OK) return rc;
+    build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data());
     return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
@@ -288,6 +343,7 @@ int sa_create(int device, sa_handle **out)
         std::vector<float> tr, pa;
         transpose_window(half, tr);
         pass_a_window(half, pa);
+        h->half_win = half;
         SA_HIPC(hipMemcpy(h->d_win_b, pa.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_win_t, tr.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
         std::vector<float4> ta(16 * 256), tb(8 * 16);
@@ -316,10 +372,12 @@ int sa_create(int device, sa_handle **out)
     {
         double sos[36];
         sos_from_q7(kDefaultQ7, sos);
-        build_plan(sos, 6, &h->plan_default, &h->lt_default);
+        build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data());
         SA_HIPC(hipMemcpy(h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
         sos_from_q7(h->c12_custom, sos);
-        build_plan(sos, 6, &h->plan_custom, &h->lt_custom);
+        std::memcpy(h->sos_custom, sos, sizeof sos);
+        h->nsec_custom = 6;
+        build_plan(sos, 6, &h->plan_custom, &h->lt_custom, h->half_win.data());
         SA_HIPC(hipMemcpy(h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
     }
     // integer tables
@@ -575,7 +633,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     SA_HIP(h, hipSetDevice(h->device));
     // The section coefficients travel by value in the kernel arguments (stream-ordered by
     // construction); only the small per-lane table lives in device memory.
-    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, nullptr, nullptr};
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, h->d_lt_custom, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;
@@ -615,9 +673,9 @@ int sa_iir_plan_from_sos(const double *sos, int n_sections, float *out, int cap)
         for (int i = 0; i < 6; ++i) norm[6 * s + i] = sos[6 * s + i] / a0;
     }
     SaIirK p;
-    SaIirLaneTab lt;
-    build_plan(norm, n_sections, &p, &lt);
-    return export_plan(p, lt, out, cap);
+    std::vector<SaIirLaneTab> lt(1);
+    build_plan(norm, n_sections, &p, &lt[0], nullptr);
+    return export_plan(p, lt[0], out, cap);
 }
 
 }  // extern "C"

@@ -99,6 +99,8 @@ def _parse_plan(plan):
     """Flat view written by sa_iir_plan_from_sos: SaIirK (nsec, pad[3], 6 x {c[8], pc[4], plev[4][4],
     prow[4][4]}) followed by SaIirLaneTab {m[6][32][2], p[6][16][4]}."""
     nsec = int(plan[:1].view(np.int32)[0])
+    unit = int(plan[1:2].view(np.int32)[0])
+    gain = float(plan[2]) if unit else 1.0
     off, secs = 4, []
     for _ in range(6):
         c = plan[off:off + 8]; off += 8
@@ -111,7 +113,7 @@ def _parse_plan(plan):
         secs[i][4] = mt[i]
     lt = plan[off:off + 6 * 64].reshape(6, 16, 4); off += 6 * 64
     assert off == plan.size
-    return nsec, secs, lt
+    return nsec, secs, lt, np.float32(gain)
 
 
 def _ks(z, mats):
@@ -131,8 +133,8 @@ def emulate_chunked_iir(plan, x):
     A,B of 32; per section: predict -> in-row scan (16 threads) -> scan over the 16 row totals ->
     start states -> DF2T recursion on both chunks."""
     f = np.float32
-    nsec, secs, lt = _parse_plan(plan)
-    v = x.astype(f).reshape(256, 2, 32).copy()              # [thread][chunk][j]
+    nsec, secs, lt, gain = _parse_plan(plan)
+    v = (x.astype(f) * gain).astype(f).reshape(256, 2, 32).copy()   # unit form: cascade gain folded into the window              # [thread][chunk][j]
     for s in range(nsec):
         c, pc, plev, prow, m = secs[s]
         z = np.zeros((256, 2, 2), f)                         # [thread][chunk][state]
@@ -179,6 +181,15 @@ def test_iir_plan_reproduces_sosfilt(hip_lib_built, oracle):
         ref = sosfilt(sos, xw.astype(np.float64))
         y = emulate_chunked_iir(plan, xw)
         assert rel_maxnorm(y[None, :], ref[None, :]) <= 1e-5
+    # the Butterworth cascade is eligible for the unit-numerator form (b2 == b0 in every section) ...
+    assert int(plan[1:2].view(np.int32)[0]) == 1 and abs(float(plan[2]) - np.prod(sos[:, 0])) <= 1e-6 * np.prod(sos[:, 0])
+    # ... the RTL default taps (b2 = -b0) or a padded 3-section cascade are not, and take the general path
+    rtl = np.array([[14 / 128, 0, -14 / 128, 1, 21 / 128, 107 / 128], [15 / 128, 0, -15 / 128, 1, -21 / 128, 107 / 128]])
+    for other in (rtl, sos[:3]):
+        p2 = iir_plan_from_sos(other)
+        assert int(p2[1:2].view(np.int32)[0]) == 0
+        xw = (g["x"][0].astype(np.float64) * hann).astype(np.float32)
+        assert rel_maxnorm(emulate_chunked_iir(p2, xw)[None, :], sosfilt(other, xw.astype(np.float64))[None, :]) <= 1e-5
 
 
 def test_iir_plan_rejects_bad_sos(hip_lib_built):
