@@ -297,14 +297,18 @@ __device__ __forceinline__ void split_store(const cf (&P)[5], const cf (&Q)[5], 
     }
 }
 
-// position of Z[k] inside the half image of the natural-order exchange (round = half of d = k>>9:
-// round 0 holds d in {0..3, 12..15}, round 1 holds d in {4..11}; both map d to d' = 0..7)
-__device__ __forceinline__ int zpos(int k, int round)
+// Position of Z[k] inside the half image of the natural-order exchange.  Round r holds the rows
+// d = k >> 9 of {0..3, 12..15} (r = 0) or {4..11} (r = 1), compacted to d' = (d + 4r) & 7; inside a row
+// the 512 entries are padded by one per 32.  With q = k - 2048 r for the low member of a pair and
+// w = 2048 - q for its partner 8192 - k, the compacted row is the same expression in both rounds:
+//   low  member: row = q >> 9            partner: row = (4 + (w >> 9)) & 7
+__device__ __forceinline__ int zrow_pos(int within, int row)
 {
-    const int dd = ((k >> 9) + 4 * round) & 7;
-    const int rest = k & 511;
-    return rest + (rest >> 5) + 528 * dd;
+    const int rest = within & 511;
+    return rest + (rest >> 5) + 528 * row;
 }
+__device__ __forceinline__ int zpos_low(int q) { return zrow_pos(q, q >> 9); }
+__device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w >> 9)) & 7); }
 
 // ---------------------------------------------------------------------------------------------
 template <int NSEC, bool UNIT, int OUT>
@@ -481,22 +485,27 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
         SA_STAMP(9 + r);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int k0 = 4 * (t + 256 * jj + 512 * r);
+            const int q0 = 4 * (t + 256 * jj);                 // k0 - 2048 r: bins q0 .. q0+4 of this round
+            const int k0 = q0 + 2048 * r;
             const float4 w01 = *reinterpret_cast<const float4 *>(twP + k0);
             const float4 w23 = *reinterpret_cast<const float4 *>(twP + k0 + 2);
             const float2 w4 = twP[k0 + 4];
             const cf w[5] = {{w01.x, w01.y}, {w01.z, w01.w}, {w23.x, w23.y}, {w23.z, w23.w}, {w4.x, w4.y}};
+            // a group of four bins never straddles a padding or row boundary, so four positions serve
+            // the ten reads: low members q0+e at pa+e (e<4) and pb; partners at pm0, pm4+3, pm4+2, pm4+1, pm4
+            const int pa = zpos_low(q0), pb = zpos_low(q0 + 4);
+            const int pm0 = zpos_partner(2048 - q0), pm4 = zpos_partner(2044 - q0);
+            cf zk[5] = {ldc[pa], ldc[pa + 1], ldc[pa + 2], ldc[pa + 3], ldc[pb]};
+            cf zm[5] = {ldc[pm0], ldc[pm4 + 3], ldc[pm4 + 2], ldc[pm4 + 1], ldc[pm4]};
+            // the seam pair (2048, 6144): Z[2048] is not in round 0's image, Z[6144] not in round 1's
+            if (r == 0 && q0 == 2044) {
+                zk[4] = side[1];
+                zm[4] = side[0];
+            }
+            if (r == 1 && q0 == 0) zm[0] = side[0];
             cf P[5], Q[5];
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
-                const int k = k0 + e;
-                const int km = (SA_MC - k) & (SA_MC - 1);
-                cf zk = ldc[zpos(k, r)];
-                cf zm = ldc[zpos(km, r)];
-                if (r == 0 && k == 2048) zk = side[1];
-                if (km == 6144) zm = side[0];
-                split_eval(zk, zm, w[e], P[e], Q[e]);
-            }
+            for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], P[e], Q[e]);
             split_store<OUT>(P, Q, out, f, k0);
         }
     }
