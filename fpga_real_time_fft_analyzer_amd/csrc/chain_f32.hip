@@ -145,25 +145,36 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     // state after both chunks of this thread, from zero state: zT = Pc zA + zB
     float t1 = __builtin_fmaf(k.pc[0], z1.x, __builtin_fmaf(k.pc[1], z2.x, z1.y));
     float t2 = __builtin_fmaf(k.pc[2], z1.x, __builtin_fmaf(k.pc[3], z2.x, z2.y));
-    // inclusive affine scan inside the 16-lane row
-    scan_level<1>(t1, t2, k.plev[0]);
-    scan_level<2>(t1, t2, k.plev[1]);
-    scan_level<4>(t1, t2, k.plev[2]);
-    scan_level<8>(t1, t2, k.plev[3]);
+    // inclusive affine scan inside the 16-lane row; levels whose transition power has decayed below
+    // float resolution are skipped (wave-uniform flags from the host)
+    const int flags = k.flags;
+    if (!(flags & 1)) scan_level<1>(t1, t2, k.plev[0]);
+    if (!(flags & 2)) scan_level<2>(t1, t2, k.plev[1]);
+    if (!(flags & 4)) scan_level<4>(t1, t2, k.plev[2]);
+    if (!(flags & 8)) scan_level<8>(t1, t2, k.plev[3]);
     const int row = 4 * wave + (lane >> 4);
     if ((lane & 15) == 15) scr_s[row] = make_float2(t1, t2);
     const float e1 = row_shr<1>(t1), e2 = row_shr<1>(t2);       // exclusive: state before this thread, row-local
     lds_barrier();
-    // scan over the 16 row totals (every row of every wave repeats it: 16 lanes, 4 DPP levels)
-    const float2 tt = scr_s[lane & 15];
-    float r1 = tt.x, r2 = tt.y;
-    scan_level<1>(r1, r2, k.prow[0]);
-    scan_level<2>(r1, r2, k.prow[1]);
-    scan_level<4>(r1, r2, k.prow[2]);
-    scan_level<8>(r1, r2, k.prow[3]);
-    // state at the start of this lane's row = inclusive result of the previous row
-    const int src = (lane & 48) | ((row - 1) & 15);
-    float c1 = lane_get(r1, src), c2 = lane_get(r2, src);
+    float c1, c2;
+    if (flags & SA_IIR_SKIP_ROWSCAN) {
+        // a row (1024 samples) outlasts the section's memory: the row starts from the previous row's total
+        const float2 tt = scr_s[(row - 1) & 15];
+        c1 = tt.x;
+        c2 = tt.y;
+    } else {
+        // scan over the 16 row totals (every row of every wave repeats it: 16 lanes, 4 DPP levels)
+        const float2 tt = scr_s[lane & 15];
+        float r1 = tt.x, r2 = tt.y;
+        scan_level<1>(r1, r2, k.prow[0]);
+        scan_level<2>(r1, r2, k.prow[1]);
+        scan_level<4>(r1, r2, k.prow[2]);
+        scan_level<8>(r1, r2, k.prow[3]);
+        // state at the start of this lane's row = inclusive result of the previous row
+        const int src = (lane & 48) | ((row - 1) & 15);
+        c1 = lane_get(r1, src);
+        c2 = lane_get(r2, src);
+    }
     if (row == 0) {
         c1 = 0.f;
         c2 = 0.f;

@@ -15,8 +15,14 @@
 // with state transition A = [[-a1,1],[-a2,0]] and input vector Bv = [b1 - a1 b0, b2 - a2 b0].
 // Pc = A^32 (one chunk), P2 = A^64 (one thread = two chunks), Prow = A^1024 (one 16-lane row).
 // Everything here is wave-uniform and travels in the kernel argument segment (SGPRs).
+// flags: bit i (i = 0..3) set = in-row scan level 2^i is skipped because P2^(2^i) is below float
+// resolution (|entries| < 1e-10: its contribution is < 1e-10 of the state); bit 4 set = the same holds
+// for Prow, so the start state of a row is just the previous row's total (no scan over the rows).
+#define SA_IIR_SKIP_ROWSCAN 16
 struct SaIirSecK {
-    float c[8];            // b0,b1,b2,a1,a2,0,0,0
+    float c[5];            // b0,b1,b2,a1,a2
+    int flags;
+    float pad[2];
     float pc[4];           // Pc, row-major p00,p01,p10,p11
     float plev[4][4];      // P2^(1,2,4,8)      in-row scan (DPP row_shr 1,2,4,8)
     float prow[4][4];      // Prow^(1,2,4,8)    scan over the 16 rows of a frame

@@ -107,9 +107,15 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         const Mat2 Prow = mpow(P2, 16);                     // one 16-lane row
         put(sp.pc, Pc);
         Mat2 q = P2, qr = Prow;
+        auto tiny = [](const Mat2 &m) {
+            const double mx = std::fmax(std::fmax(std::fabs(m.a), std::fabs(m.b)), std::fmax(std::fabs(m.c), std::fabs(m.d)));
+            return mx < 1e-10;
+        };
+        sp.flags = tiny(Prow) ? SA_IIR_SKIP_ROWSCAN : 0;
         for (int i = 0; i < 4; ++i) {                       // powers 1,2,4,8
             put(sp.plev[i], q);
             put(sp.prow[i], qr);
+            if (tiny(q)) sp.flags |= 1 << i;
             q = mul(q, q);
             qr = mul(qr, qr);
         }

@@ -103,7 +103,7 @@ def _parse_plan(plan):
     gain = float(plan[2]) if unit else 1.0
     off, secs = 4, []
     for _ in range(6):
-        c = plan[off:off + 8]; off += 8
+        c = plan[off:off + 8]; off += 8        # b0,b1,b2,a1,a2, flags (int), pad, pad
         pc = plan[off:off + 4]; off += 4
         plev = plan[off:off + 16].reshape(4, 4); off += 16
         prow = plan[off:off + 16].reshape(4, 4); off += 16
