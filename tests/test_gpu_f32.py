@@ -216,3 +216,34 @@ def test_full_size_properties(ch, torch_mod):
     idx = [0, 1023, 2048, 4095]
     _, X, _ = o.chain_fp(x[idx].cpu().numpy(), g["sos"])
     assert np.abs(s[idx].cpu().numpy() - X).max(axis=1).max() <= TOL * np.abs(X).max()
+
+
+def test_side_stream_and_graph_replay(ch, torch_mod, oracle):
+    """Calls are asynchronous on the caller's stream and capturable into a HIP graph (no allocation,
+    no synchronisation inside sa_process_f32 once the kernels have been used once)."""
+    torch = torch_mod
+    g = load_golden("g2_config1.npz")
+    ch.load_sos(g["sos"])
+    ch.set_filter_mode(0xA1)
+    x = _dev(torch, synth(8, seed=31))
+    ref = ch.process_f32(x).clone()                       # warm-up on the default stream
+    out = torch.empty_like(ref)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ch.process_f32(x, out=out)
+    s.synchronize()
+    assert torch.equal(out, ref)
+    graph = torch.cuda.CUDAGraph()
+    out.zero_()
+    with torch.cuda.graph(graph):
+        ch.process_f32(x, out=out)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    x.copy_(_dev(torch, synth(8, seed=32)))               # new data, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    _, _, mag = oracle.chain_fp(x.cpu().numpy(), g["sos"])
+    assert rel_maxnorm(out.cpu().numpy(), mag) <= TOL
