@@ -235,6 +235,21 @@ __device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool 
     return pack2(sat16(pr), sat16(pi));
 }
 
+// one radix-4 DIF butterfly of SA-FXFFT-1 on packed (re, im) int16 pairs: 32-bit sums, >> 2 (truncation),
+// Q15 twiddles on outputs 1..3 (exact pass-through when the exponent is 0), saturation to int16
+__device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, unsigned w1, unsigned w2,
+                                             unsigned w3, bool unity, unsigned (&o)[4])
+{
+    const int ar = lo16(a), ai = hi16(a), br = lo16(b), bi = hi16(b);
+    const int cr = lo16(c), ci = hi16(c), dr = lo16(d), di = hi16(d);
+    const int sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;      // a +/- c
+    const int ur = br + dr, ui = bi + di, vr = br - dr, vi = bi - di;      // b +/- d
+    o[0] = pack2(sat16((sr + ur) >> 2), sat16((si + ui) >> 2));
+    o[1] = fx_twiddle((tr + vi) >> 2, (ti - vr) >> 2, w1, unity);          // a - i b - c + i d
+    o[2] = fx_twiddle((sr - ur) >> 2, (si - ui) >> 2, w2, unity);
+    o[3] = fx_twiddle((tr - vi) >> 2, (ti + vr) >> 2, w3, unity);          // a + i b - c - i d
+}
+
 template <bool WINDOW>
 __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
                                                                   int16_t *__restrict__ out_iq, int batch,
@@ -245,7 +260,10 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
     unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
     const int t = threadIdx.x;
 
-    for (int f = blockIdx.x; f < batch; f += gridDim.x) {
+    {
+        // one frame per workgroup (a frame loop lets the compiler hoist loop-invariant addresses: spills)
+        const int f = blockIdx.x;
+        if (f >= batch) return;
         // ---- load: 8 samples per 16-byte read, optional window, imag = 0 (new/command_control.vhd:123)
         const uint4 *x4 = reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS);
         const uint4 *c4 = reinterpret_cast<const uint4 *>(rom);
@@ -285,47 +303,63 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
         //   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
         //   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
         //   output i' at (j' << (2s+2)) | (i' << 2s) | kappa; twiddle exponent i' * j' * 4^s.
-        for (int s = 0; s < 7; ++s) {
+        // Thread t owns the 64 positions t + 256 m.  Stages 0..3 scatter their outputs to other threads
+        // (one LDS pass each); from stage 4 on (4^s >= 256) every output stays with its thread, so
+        // stages 4, 5, 6 run in registers and the result is stored straight from them.
+        unsigned v[64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             const int sh = 2 * s;
-            unsigned v[16][4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int bf = t + 256 * u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[u][i] = buf[bf + 4096 * i];
-            }
+            for (int m = 0; m < 64; ++m) v[m] = buf[t + 256 * m];      // m = u + 16 i
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int bf = t + 256 * u;
-                const int jp = bf >> sh;
+                // stage 3: j' = (t >> 6) + 4u is the same for the whole wave -> scalar twiddle loads
+                const int jp = (s == 3) ? (__builtin_amdgcn_readfirstlane(t >> 6) + 4 * u) : (bf >> sh);
                 const int kap = bf & ((1 << sh) - 1);
-                const int ar = lo16(v[u][0]), ai = hi16(v[u][0]);
-                const int br = lo16(v[u][1]), bi = hi16(v[u][1]);
-                const int cr = lo16(v[u][2]), ci = hi16(v[u][2]);
-                const int dr = lo16(v[u][3]), di = hi16(v[u][3]);
-                const int t0r = ar + br + cr + dr, t0i = ai + bi + ci + di;
-                const int t1r = ar + bi - cr - di, t1i = ai - br - ci + dr;
-                const int t2r = ar - br + cr - dr, t2i = ai - bi + ci - di;
-                const int t3r = ar - bi - cr + di, t3i = ai + br - ci - dr;
-                const int e1 = jp << sh;                       // exponent of W_N for i' = 1
-                const bool unity = (e1 == 0);
-                const unsigned w1 = tw[e1], w2 = tw[2 * e1], w3 = tw[3 * e1];
+                const int e1 = jp << sh;
+                unsigned o[4];
+                fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o);
                 const int ob = (jp << (sh + 2)) | kap;
-                buf[ob] = pack2(sat16(t0r >> 2), sat16(t0i >> 2));
-                buf[ob + (1 << sh)] = fx_twiddle(t1r >> 2, t1i >> 2, w1, unity);
-                buf[ob + (2 << sh)] = fx_twiddle(t2r >> 2, t2i >> 2, w2, unity);
-                buf[ob + (3 << sh)] = fx_twiddle(t3r >> 2, t3i >> 2, w3, unity);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
             }
             __syncthreads();
         }
-
-        // ---- natural-order frame out: [16384] x (re, im) int16 = 65536 bytes (imp/sequ2.vhd:153)
-        uint4 *o4 = reinterpret_cast<uint4 *>(out_iq + (size_t)f * SA_NPTS * 2);
-        const uint4 *b4 = reinterpret_cast<const uint4 *>(buf);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o4[t + 256 * i] = b4[t + 256 * i];
-        __syncthreads();
+        for (int m = 0; m < 64; ++m) v[m] = buf[t + 256 * m];
+        unsigned w[64];
+        // stage 4 (4^s = 256): j' = u, kappa = t; outputs land at m' = 4u + i'; exponents are compile-time
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            unsigned o[4];
+            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[u * 256], tw[2 * u * 256], tw[3 * u * 256], u == 0, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
+        }
+        // stage 5 (4^s = 1024): j' = u >> 2, kappa = t + 256 (u & 3); outputs at m' = 16 (u>>2) + 4 i' + (u&3)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            unsigned o[4];
+            const int jp = u >> 2;
+            fx_butterfly(w[u], w[u + 16], w[u + 32], w[u + 48], tw[jp * 1024], tw[2 * jp * 1024], tw[3 * jp * 1024],
+                         jp == 0, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[16 * jp + 4 * i + (u & 3)] = o[i];
+        }
+        // stage 6 (4^s = 4096): no twiddles; outputs at m' = u + 16 i' = natural-order bin t + 256 m'
+        // frame layout: [16384] x (re, im) int16 = 65536 bytes (imp/sequ2.vhd:153); one dword per lane,
+        // 256 contiguous bytes per wave instruction
+        unsigned *o32 = reinterpret_cast<unsigned *>(out_iq + (size_t)f * SA_NPTS * 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            unsigned o[4];
+            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], 0u, 0u, 0u, true, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o32[t + 256 * (u + 16 * i)] = o[i];
+        }
     }
 }
 
