@@ -95,20 +95,35 @@ struct BiqQ14 {
 };
 
 // window + stage one tile of 8 frames x 256 samples into LDS (16 B per lane, two rows per instruction)
-__device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, const int16_t *__restrict__ rom,
-                                               int16_t (*tin)[kRowPitch], int f0, int batch, int n0, int lane,
-                                               int win_mode)
+struct Q15TileRegs {
+    uint4 x[kFramesPerWave / 2];
+    uint4 c[kFramesPerWave / 2];
+};
+
+// issue the global loads of one tile (4 frames x 256 samples and the matching ROM words), 16 B per lane
+__device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, const int16_t *__restrict__ rom, int f0,
+                                              int batch, int n0, int lane, Q15TileRegs &r)
 {
 #pragma unroll
     for (int i = 0; i < kFramesPerWave / 2; ++i) {
         const int row = 2 * i + (lane >> 5);
         const int col = (lane & 31) * 8;
         const int f = f0 + row;
-        uint4 xv = make_uint4(0, 0, 0, 0);
-        if (f < batch) xv = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
-        const uint4 cv = *reinterpret_cast<const uint4 *>(rom + n0 + col);
-        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
+        r.x[i] = make_uint4(0, 0, 0, 0);
+        if (f < batch) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
+        r.c[i] = *reinterpret_cast<const uint4 *>(rom + n0 + col);
+    }
+}
+
+// window the loaded tile and put it into LDS
+__device__ __forceinline__ void q15_store_tile(const Q15TileRegs &r, int16_t (*tin)[kRowPitch], int lane, int win_mode)
+{
+#pragma unroll
+    for (int i = 0; i < kFramesPerWave / 2; ++i) {
+        const int row = 2 * i + (lane >> 5);
+        const int col = (lane & 31) * 8;
+        const unsigned xs[4] = {r.x[i].x, r.x[i].y, r.x[i].z, r.x[i].w};
+        const unsigned cs[4] = {r.c[i].x, r.c[i].y, r.c[i].z, r.c[i].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int a, b;
@@ -122,6 +137,15 @@ __device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, c
             *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
         }
     }
+}
+
+__device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, const int16_t *__restrict__ rom,
+                                               int16_t (*tin)[kRowPitch], int f0, int batch, int n0, int lane,
+                                               int win_mode)
+{
+    Q15TileRegs r;
+    q15_load_tile(in, rom, f0, batch, n0, lane, r);
+    q15_store_tile(r, tin, lane, win_mode);
 }
 
 template <int PITCH>
@@ -156,7 +180,6 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
 {
     __shared__ __attribute__((aligned(16))) int16_t tin[kFramesPerWave][kRowPitch];
     __shared__ __attribute__((aligned(16))) int16_t ring[kFramesPerWave][kRingPitch];
-    __shared__ int16_t trash[64];
     const int lane = threadIdx.x;
     const int fr = lane >> 4;           // frame slot in this wave
     const int sec = lane & 15;          // section index (6..15 idle)
@@ -174,46 +197,57 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
 
     using Biq = typename std::conditional<WIDE, BiqQ14, BiqQ7>::type;
     Biq bq{};
-    int last_sec = 5;
+    // Lanes 0..5 (or 0..nsec-1) of the row run the real sections; lanes up to 8 run identity sections so
+    // that the output appears at lane 8 with a delay of exactly 8 steps: every group of 8 steps then
+    // delivers 8 consecutive, 16-byte aligned samples -> one ds_write_b128 instead of 8 short stores.
+    const int nreal = WIDE ? prm.nsec_wide : 6;
     if constexpr (WIDE) {
-        last_sec = prm.nsec_wide - 1;
-        if (sec < prm.nsec_wide) {
+        if (sec < nreal) {
             const int16_t *c = &prm.sos_q14[sec * 6];
             bq.b0 = c[0]; bq.b1 = c[1]; bq.b2 = c[2]; bq.a1 = c[4]; bq.a2 = c[5];
-        }                                   // idle lanes keep all-zero taps: output 0
+        } else {
+            bq.b0 = 16384; bq.b1 = bq.b2 = bq.a1 = bq.a2 = 0;      // (16384 x + 8192) >> 14 = x exactly
+        }
     } else {
-        if (sec < 6) {
+        if (sec < nreal) {
             const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
             bq.cB0 = c[0]; bq.cB1 = c[1]; bq.cB2 = c[2]; bq.nA0 = -(int)c[3]; bq.nA1 = -(int)c[4];
         } else {
-            bq.cB0 = bq.cB1 = bq.cB2 = bq.nA0 = bq.nA1 = 0;
+            bq.cB2 = 128; bq.cB0 = bq.cB1 = bq.nA0 = bq.nA1 = 0;   // (128 x) >> 7 = x exactly
         }
     }
-    // only the last section's lane stores; the others write to a private trash slot (stride 0)
-    const bool is_last = sec == last_sec;
-    int16_t *wbase = is_last ? &ring[fr][0] : &trash[lane];
-    const int wstride = is_last ? 1 : 0;
+    constexpr int kOutLane = 8;
+    const bool is_out = sec == kOutLane;
     int yprev = 0;
 
+    Q15TileRegs pre;
+    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
     for (int k = 0; k <= SA_NPTS / kTile; ++k) {   // one extra block drains the pipeline
         const bool live = k < SA_NPTS / kTile;
-        if (live) q15_stage_tile(in, rom, tin, f0, batch, k * kTile, lane, prm.win_mode);
+        if (live) q15_store_tile(pre, tin, lane, prm.win_mode);
         __syncthreads();
+        // the next tile's HBM reads fly while this tile is being filtered
+        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
         const int nsteps = live ? kTile / 8 : 1;
+        uint4 pk = make_uint4(0, 0, 0, 0);
+        if (live) pk = *reinterpret_cast<const uint4 *>(&tin[fr][0]);
         for (int g = 0; g < nsteps; ++g) {
-            uint4 pk = make_uint4(0, 0, 0, 0);
-            if (live) pk = *reinterpret_cast<const uint4 *>(&tin[fr][8 * g]);
             const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+            if (live && g + 1 < nsteps) pk = *reinterpret_cast<const uint4 *>(&tin[fr][8 * (g + 1)]);   // one group ahead
+            int ys[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int T = k * kTile + 8 * g + e;
                 const int xin = (e & 1) ? hi16(w[e >> 1]) : lo16(w[e >> 1]);
                 // lane 0 of the row has no left neighbour: bound_ctrl = false keeps `old` = xin there
                 const int x = __builtin_amdgcn_update_dpp(xin, yprev, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-                const int y = bq.step(x);
-                yprev = y;
-                wbase[((T - last_sec) & (kRing - 1)) * wstride] = (int16_t)y;
+                yprev = bq.step(x);
+                ys[e] = yprev;
             }
+            // lane 8 holds samples T0 .. T0+7 with T0 = 256k + 8g - 8 (nothing valid before the first group)
+            const int T0 = k * kTile + 8 * g - kOutLane;
+            if (is_out && T0 >= 0)
+                *reinterpret_cast<uint4 *>(&ring[fr][T0 & (kRing - 1)]) =
+                    make_uint4(pack2(ys[0], ys[1]), pack2(ys[2], ys[3]), pack2(ys[4], ys[5]), pack2(ys[6], ys[7]));
         }
         __syncthreads();
         if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
