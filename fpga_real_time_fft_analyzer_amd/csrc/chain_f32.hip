@@ -117,6 +117,8 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         const int sw = (t >> 1) & 7;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
+            // two batches of four units: all eight in flight at once push the kernel over 128 VGPRs
+            if (g == 4) __builtin_amdgcn_sched_barrier(0);
             const float4 w = wint[(8 * h + g) * 256 + t];
             const float4 q = lds4[t * 8 + (g ^ sw)];
             if (h == 0) {
