@@ -30,8 +30,7 @@ constexpr int kThreads = 256;
 constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange image (4352 complex)
 constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 sections x 16 rows x float2
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
-constexpr int kMtabOff = kSideOff + 16;               // two complex side slots, then the predictor taps
-constexpr int kLdsBytes = kMtabOff + SA_MAXSEC * SA_CHUNK * 4 * 4;   // taps stored as (m1,m1,m2,m2)
+constexpr int kLdsBytes = kSideOff + 16;              // two complex side slots
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 
@@ -85,6 +84,13 @@ __device__ __forceinline__ void scan_level(float &z1, float &z2, const float (&p
     z2 = __builtin_fmaf(p[2], u1, __builtin_fmaf(p[3], u2, z2));
 }
 
+__device__ __forceinline__ float mul_to(float a, float b)
+{
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage-in for the IIR, two rounds.  Round h brings chunk h (32 samples = 128 B) of every thread:
 // the samples go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write), 1 KiB = 8 rows
@@ -104,6 +110,7 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1) __syncthreads();          // round-0 readers are done with the image
+        __builtin_amdgcn_s_setprio(3);        // get the requests out ahead of the other workgroups' arithmetic
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = wave * 8 + i;                        // slab: rows 8n .. 8n+7
@@ -113,6 +120,7 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();                      // waits for the DMA (vmcnt) and publishes the image
         const int sw = (t >> 1) & 7;
 #pragma unroll
@@ -121,16 +129,18 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
             if (g == 4) __builtin_amdgcn_sched_barrier(0);
             const float4 w = wint[(8 * h + g) * 256 + t];
             const float4 q = lds4[t * 8 + (g ^ sw)];
+            // mul_to: one v_mul_f32 straight into its half of the (chunk A, chunk B) pair.  Left to the
+            // SLP vectoriser the two rounds become v_pk_mul_f32 on re-paired operands: ~100 v_mov per thread.
             if (h == 0) {
-                d[4 * g + 0].x = q.x * w.x;
-                d[4 * g + 1].x = q.y * w.y;
-                d[4 * g + 2].x = q.z * w.z;
-                d[4 * g + 3].x = q.w * w.w;
+                d[4 * g + 0].x = mul_to(q.x, w.x);
+                d[4 * g + 1].x = mul_to(q.y, w.y);
+                d[4 * g + 2].x = mul_to(q.z, w.z);
+                d[4 * g + 3].x = mul_to(q.w, w.w);
             } else {
-                d[4 * g + 0].y = q.x * w.x;
-                d[4 * g + 1].y = q.y * w.y;
-                d[4 * g + 2].y = q.z * w.z;
-                d[4 * g + 3].y = q.w * w.w;
+                d[4 * g + 0].y = mul_to(q.x, w.x);
+                d[4 * g + 1].y = mul_to(q.y, w.y);
+                d[4 * g + 2].y = mul_to(q.z, w.z);
+                d[4 * g + 3].y = mul_to(q.w, w.w);
             }
         }
     }
@@ -141,7 +151,7 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 //   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
 //   z1,z2 (out): the same for the NEXT section (accumulated while this section's outputs appear)
 template <bool PREDICT_NEXT, bool UNIT>
-__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float4 *mt_next,
+__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float2 *__restrict__ mt_next,
                                             const float4 lanep, float2 *scr_s, int lane, int wave, v2f &z1, v2f &z2)
 {
     // state after both chunks of this thread, from zero state: zT = Pc zA + zB
@@ -204,10 +214,11 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
         }
         d[j] = y;
         if constexpr (PREDICT_NEXT) {
-            const float4 mm = mt_next[j];                     // wave-uniform LDS broadcast (m1,m1,m2,m2)
-            const v2f m1 = {mm.x, mm.y}, m2 = {mm.z, mm.w};
-            n1 = safft::pk_fma(m1, y, n1);
-            n2 = safft::pk_fma(m2, y, n2);
+            // wave-uniform address: the taps arrive through scalar loads and feed the packed FMAs as
+            // SGPR operands (as LDS broadcasts they cost 40 % of the kernel's LDS cycles)
+            const float2 mm = mt_next[j];
+            n1 += mm.x * y;
+            n2 += mm.y * y;
         }
     }
     z1 = n1;
@@ -219,43 +230,33 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
 // through control-flow merges and cost ~190 register copies.
 template <int S, int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
-                                             const float4 *mtab, float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
+                                             float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
 {
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
         if constexpr (S + 1 < NSEC)
-            iir_section<true, UNIT>(d, ka.sec[S], mtab + 32 * (S + 1), lanep, scr + 16 * S, lane, wave, z1, z2);
+            iir_section<true, UNIT>(d, ka.sec[S], reinterpret_cast<const float2 *>(&lt->m[S + 1][0][0]), lanep,
+                                    scr + 16 * S, lane, wave, z1, z2);
         else
-            iir_section<false, UNIT>(d, ka.sec[S], mtab, lanep, scr + 16 * S, lane, wave, z1, z2);
-        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, mtab, scr, lane, wave, z1, z2);
+            iir_section<false, UNIT>(d, ka.sec[S], nullptr, lanep, scr + 16 * S, lane, wave, z1, z2);
+        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, z1, z2);
     }
 }
 
-// mtab: LDS copy of SaIirLaneTab::m (predictor taps), [section][32] float4 = (m1[j],m1[j],m2[j],m2[j])
 template <int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
-                                            const float4 *mtab, float2 *scr, int t)
+                                            float2 *scr, int t)
 {
     // predictor for the first section (later ones are fused into the recursion loops)
     v2f z1 = {0.f, 0.f}, z2 = {0.f, 0.f};
+    const float2 *__restrict__ m0 = reinterpret_cast<const float2 *>(&lt->m[0][0][0]);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const float4 mm = mtab[j];
-        const v2f m1 = {mm.x, mm.y}, m2 = {mm.z, mm.w};
-        z1 = safft::pk_fma(m1, d[j], z1);
-        z2 = safft::pk_fma(m2, d[j], z2);
+        const float2 mm = m0[j];
+        z1 += mm.x * d[j];
+        z2 += mm.y * d[j];
     }
-    iir_sections<0, NSEC, UNIT>(d, ka, lt, mtab, scr, t & 63, t >> 6, z1, z2);
-}
-
-// copy the predictor taps into LDS as (m1,m1,m2,m2) per tap (first 192 threads, one tap each); visible
-// to everybody after the first barrier of stage_in_chunks
-__device__ __forceinline__ void load_mtab(const SaIirLaneTab *__restrict__ lt, float4 *mtab, int t)
-{
-    if (t < SA_MAXSEC * SA_CHUNK) {
-        const float2 m = reinterpret_cast<const float2 *>(&lt->m[0][0][0])[t];
-        mtab[t] = make_float4(m.x, m.x, m.y, m.y);
-    }
+    iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, z1, z2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,11 +355,9 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 
     if constexpr (IIR) {
         v2f d[32];
-        float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
-        load_mtab(lanetab, mtab, t);
         stage_in_chunks(xin, reinterpret_cast<const float4 *>(lanetab->win_t), smem, t, d);
         SA_STAMP(1);
-        iir_cascade<NSEC, UNIT>(d, ka, lanetab, mtab, scr, t);
+        iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
         // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
@@ -394,6 +393,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1) __syncthreads();
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int n = wave * 8 + i;
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
@@ -543,11 +544,9 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     const int f = blockIdx.x;
     if (f >= batch) return;
     v2f d[32];
-    float4 *mtab = reinterpret_cast<float4 *>(smem + kMtabOff);
-    if constexpr (NSEC > 0) load_mtab(lanetab, mtab, t);
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
     stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
-    if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, mtab, scr, t);
+    if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
     float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)

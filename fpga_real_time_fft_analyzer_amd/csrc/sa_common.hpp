@@ -39,7 +39,7 @@ struct SaIirK {
 
 // device-memory part of the plan:
 //   m[s][j]   = predictor taps (m1, m2): chunk end state from zero state = sum_j m[s][j] x[j];
-//               copied into LDS at kernel start and read as wave-uniform broadcasts
+//               read at wave-uniform addresses, i.e. through scalar loads into SGPR operands
 //   p[s][i]   = P2^i, i = lane index inside its 16-lane row (start-state injection per lane)
 //   win_t     = 0.5 * window * G, transposed for the chunk layout (win_t[g][t][e] = w[64t + 4g + e]);
 //               G = product of the sections' b0 when the plan is in unit-numerator form, else 1

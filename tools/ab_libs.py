@@ -30,26 +30,34 @@ for name in sys.argv[1:]:
     assert L.sa_load_sos_f64(h, sos.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
     libs.append((name, L, h))
 st = torch.cuda.current_stream().cuda_stream
-res = {}
-ref = {}
+ROUNDS, REPS = 12, 40
 for mode in (0xA1, 0xB1):
-    for rnd in range(5):
+    res, ref = {}, None
+    # sustained pre-warm so that every build is measured at the settled clock
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
         for name, L, h in libs:
             L.sa_set_filter_mode(h, mode)
-            for _ in range(2):
+            L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
+        torch.cuda.synchronize()
+    for rnd in range(ROUNDS):
+        order = libs[rnd % len(libs):] + libs[:rnd % len(libs)]          # rotate: no build always runs first
+        for name, L, h in order:
+            L.sa_set_filter_mode(h, mode)
+            for _ in range(3):
                 L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
             torch.cuda.synchronize()
             if rnd == 0:
-                if mode not in ref:
-                    ref[mode] = out.clone()
+                if ref is None:
+                    ref = out.clone()
                 else:
-                    d = (out - ref[mode]).abs().max().item() / ref[mode].abs().max().item()
-                    print(f"   {name} vs {libs[0][0]} mode 0x{mode:02X}: max rel diff {d:.2e}")
+                    d = (out - ref).abs().max().item() / ref.abs().max().item()
+                    print(f"   {name} vs {order[0][0]} mode 0x{mode:02X}: max rel diff {d:.2e}")
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(REPS):
                 L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
             torch.cuda.synchronize()
-            res.setdefault((mode, name), []).append((time.perf_counter() - t0) / 10)
+            res.setdefault(name, []).append((time.perf_counter() - t0) / REPS)
     for name, _, _ in libs:
-        v = sorted(res[(mode, name)])
-        print(f"mode 0x{mode:02X} {name:32s} median {v[len(v)//2]*1e6:8.1f} us  min {v[0]*1e6:8.1f} us  -> {B/v[len(v)//2]/1e6:6.2f} M frames/s")
+        v = sorted(res[name])
+        print(f"mode 0x{mode:02X} {name:32s} median {v[len(v)//2]*1e6:8.1f} us  min {v[0]*1e6:8.1f} us  max {v[-1]*1e6:8.1f} us  -> {B/v[len(v)//2]/1e6:6.2f} M frames/s")
