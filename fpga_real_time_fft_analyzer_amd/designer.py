@@ -73,3 +73,71 @@ def quantize_sos_q14(sos) -> np.ndarray:
     s = np.asarray(sos, np.float64).reshape(-1, 6)
     s = s / s[:, 3:4]
     return np.clip(np.rint(s * 16384.0), -32768, 32767).astype(np.int16)
+
+
+# ---------------------------------------------------------------------------------------------
+# Response preview.  The reference previews only the *unquantised* design
+# (generate_filter_response_plot, gui.py:190-230); what the hardware -- and the Q15 path of this
+# build -- actually runs is the cascade the 12 uploaded bytes mean to the RTL, which differs (tap order,
+# the x64 / >>7 gain of one half, a2 dropped, two sections used three times each).
+
+def filter_response(sos, fs: float = 100.0, worN: int = 2048):
+    """(w, h) of an SOS cascade, the numbers behind gui.py:193 (``signal.sosfreqz(sos, worN=2048, fs=fs)``)."""
+    return _sig.sosfreqz(np.asarray(sos, np.float64).reshape(-1, 6), worN=worN, fs=fs)
+
+
+def fpga_effective_sos(quantized_two_sections) -> np.ndarray:
+    """The linear filter the uploaded bytes select in the RTL, as a 6x6 scipy SOS.
+
+    One biquad computes y[n] = (B2 x[n] + B1 x[n-1] + B0 x[n-2] - A0 y[n-2] - A1 y[n-1]) / 128 with
+    every product floored separately (filter_iir_cust.vhd:96-117); the GUI's byte order
+    [b0,b1,b2,a0,a1,a2] lands on ports B0,B1,B2,A0,A1,A2, and A2 is not connected.  Sections
+    1,3,5 take bytes 0..5, sections 2,4,6 bytes 6..11 (filter_iir12_cust.vhd:68-240).  The
+    truncations are ignored here: this is the small-signal response, for preview only."""
+    secs = two_sections_for_fpga(quantized_two_sections)
+    rows = []
+    for s in secs:
+        B0, B1, B2, A0, A1, _A2 = (float(c) for c in s)
+        rows.append([B2 / 128.0, B1 / 128.0, B0 / 128.0, 1.0, A1 / 128.0, A0 / 128.0])
+    return np.asarray([rows[0], rows[1]] * 3, np.float64)
+
+
+def quantised_response(quantized_two_sections, fs: float = 100.0, worN: int = 2048):
+    """(w, h) of the cascade the FPGA-exact path runs for an upload; compare with
+    ``filter_response(design_iir_filter(...))`` to see what quantisation and the port mapping cost."""
+    return filter_response(fpga_effective_sos(quantized_two_sections), fs=fs, worN=worN)
+
+
+def generate_filter_response_plot(sos, fs: float = 100.0, quantized_two_sections=None):
+    """Magnitude/phase plot as a ``data:image/png;base64,...`` URL, like gui.py:190-230; when
+    ``quantized_two_sections`` is given the hardware's effective response is overlaid.
+    Returns None when matplotlib is not importable (the reference prints and returns None on any error)."""
+    try:
+        import base64
+        from io import BytesIO
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return None
+    w, h = filter_response(sos, fs)
+    fig, (ax_m, ax_p) = plt.subplots(2, 1, figsize=(10, 8))
+    ax_m.plot(w, 20 * np.log10(np.maximum(np.abs(h), 1e-10)), label="design (float)")
+    ax_p.plot(w, np.angle(h, deg=True))
+    if quantized_two_sections is not None:
+        wq, hq = quantised_response(quantized_two_sections, fs)
+        ax_m.plot(wq, 20 * np.log10(np.maximum(np.abs(hq), 1e-10)), label="as uploaded (12 x int8, RTL mapping)")
+        ax_p.plot(wq, np.angle(hq, deg=True))
+        ax_m.legend()
+    ax_m.set_title("Filter Frequency Response")
+    ax_m.set_ylabel("Magnitude (dB)")
+    ax_p.set_xlabel("Frequency (KHz)")
+    ax_p.set_ylabel("Phase (degrees)")
+    for ax in (ax_m, ax_p):
+        ax.grid(True, alpha=0.3)
+        ax.set_xlim(0, fs / 2)
+    fig.tight_layout()
+    buf = BytesIO()
+    fig.savefig(buf, format="png", dpi=100, bbox_inches="tight")
+    plt.close(fig)
+    return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()

@@ -49,6 +49,30 @@ def test_upload_bytes_and_padding():
     assert designer.int8_to_byte(-1) == 255 and designer.int8_to_byte(127) == 127
 
 
+def test_response_preview_tracks_the_integer_cascade(oracle):
+    """N4: the small-signal response of the uploaded bytes (RTL port mapping, two sections x 3) must
+    describe what the integer cascade does: a large-amplitude tone through the bit-exact model comes out
+    with the previewed gain (truncation noise is a few LSB per section)."""
+    from scipy import signal
+    default = [[-14, 0, 14, 107, 21, 0], [-15, 0, 15, 107, -21, 0]]          # filter_pkg.vhd:54-68
+    sos_eff = designer.fpga_effective_sos(default)
+    assert sos_eff.shape == (6, 6) and np.array_equal(sos_eff[0], sos_eff[2]) and np.array_equal(sos_eff[1], sos_eff[5])
+    assert sos_eff[0].tolist() == [14 / 128, 0.0, -14 / 128, 1.0, 21 / 128, 107 / 128]
+    n = np.arange(N)
+    for k in (3900, 4096, 4300):                                               # inside the pass band near fs/4
+        x = np.rint(12000 * np.sin(2 * np.pi * k * n / N)).astype(np.int16)
+        y = oracle.iir12_q7(x, np.array(default, np.int8).reshape(-1))
+        y_lin = signal.sosfilt(sos_eff, x.astype(np.float64))
+        assert np.max(np.abs(y[2048:] - y_lin[2048:])) <= 0.02 * np.max(np.abs(y_lin)) + 24
+    w, h = designer.quantised_response(default, fs=1000.0, worN=4096)
+    assert w[np.argmax(np.abs(h))] == pytest.approx(250.0, abs=15.0)           # band-pass near fs/4 (SURVEY IIR-3)
+    w2, h2 = designer.filter_response(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0))
+    assert len(w2) == 2048 and abs(h2[0]) == pytest.approx(1.0, rel=1e-9)      # gui.py:193 worN
+    url = designer.generate_filter_response_plot(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0), 100.0,
+                                                 quantized_two_sections=[[0, 1, 0, 64, -67, 19], [64, 127, 64, 64, -85, 40]])
+    assert url is None or url.startswith("data:image/png;base64,")
+
+
 def test_q14_quantiser(oracle):
     sos = load_golden("g2_config1.npz")["sos"]
     assert np.array_equal(designer.quantize_sos_q14(sos), oracle.quantize_sos_q14(sos))
