@@ -262,17 +262,24 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, cons
 // ---------------------------------------------------------------------------------------------
 // Split step of the packed real FFT for the bin pair (k, 8192-k):
 //   Xe = Z[k] + conj Z[M-k],  Xo = -i (Z[k] - conj Z[M-k]),  X[k] = Xe + W_N^k Xo,  X[M-k] = conj(Xe - W_N^k Xo)
-// (the 1/2 of the textbook form is already in the window table).  Returns P = X[k], Q = conj X[M-k].
-__device__ __forceinline__ void split_eval(const cf zk, const cf zm, const cf w, cf &P, cf &Q)
+// (the 1/2 of the textbook form is already in the window table).  With s = Z[k] + Z[M-k], d = Z[k] - Z[M-k]:
+//   Xe = (s.x, d.y), Xo = (s.y, -d.x), T = W Xo = s.y (w.x, w.y) + d.x (w.y, -w.x)
+// and the results come out transposed, R = (Re P, Re Q) = s.x + (T.x, -T.x), I = (Im P, Im Q) = d.y + (T.y, -T.y)
+// with P = X[k], Q = conj X[M-k]: every operand is a broadcast / swap / negation of a register pair
+// (modifiers of the packed instructions), never a pair assembled from two registers, and both squared
+// magnitudes are one packed multiply-add.
+__device__ __forceinline__ void split_eval(const cf zk, const cf zm, const cf w, cf &R, cf &I)
 {
-    const cf xe = {zk.x + zm.x, zk.y - zm.y};
-    const cf xo = {zk.y + zm.y, zm.x - zk.x};
-    const cf tw = safft::cmul(xo, w);
-    P = xe + tw;
-    Q = xe - tw;
+    const cf s = zk + zm;
+    const cf d = zk - zm;
+    // written out: the compiler assembles (w.y, -w.x) and (T.x, -T.x) with v_xor/v_mov pairs otherwise
+    cf u, tw;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(u) : "v"(s), "v"(w));                  // s.y * w
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"                         // + d.x * (w.y, -w.x)
+        : "=v"(tw) : "v"(d), "v"(w), "v"(u));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(R) : "v"(s), "v"(tw));    // s.x + (T.x, -T.x)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(I) : "v"(d), "v"(tw));    // d.y + (T.y, -T.y)
 }
-
-__device__ __forceinline__ float cabs_fast(const cf v) { return fast_sqrt(__builtin_fmaf(v.x, v.x, v.y * v.y)); }
 
 // Output of one group of bins k0..k0+4 (k0 = 4g).  The group evaluates five pairs so that all four
 // output streams (bins k, 8192-k and their mirrors 16384-k, 8192+k) leave as aligned 16-byte stores:
@@ -280,34 +287,37 @@ __device__ __forceinline__ float cabs_fast(const cf v) { return fast_sqrt(__buil
 //   [8192+k0 ..] = |Q0..3|        [8192-k0-4 ..  ] = |Q4..1|
 // Every bin of the frame is written exactly once over the 1024 groups.
 template <int OUT>
-__device__ __forceinline__ void split_store(const cf (&P)[5], const cf (&Q)[5], void *__restrict__ out, int f, int k0)
+__device__ __forceinline__ void split_store(const cf (&R)[5], const cf (&I)[5], void *__restrict__ out, int f, int k0)
 {
-    if constexpr (OUT == SA_OUT_MAG_FULL) {
-        float *o = reinterpret_cast<float *>(out) + (size_t)f * SA_NPTS;
+    if constexpr (OUT == SA_OUT_MAG_FULL || OUT == SA_OUT_MAG_HALF) {
         float mp[5], mq[5];
 #pragma unroll
         for (int e = 0; e < 5; ++e) {
-            mp[e] = cabs_fast(P[e]);
-            mq[e] = cabs_fast(Q[e]);
+            const cf m2 = safft::pk_fma(I[e], I[e], R[e] * R[e]);          // (|P|^2, |Q|^2)
+            mp[e] = fast_sqrt(m2.x);
+            mq[e] = fast_sqrt(m2.y);
         }
-        *reinterpret_cast<float4 *>(o + k0) = make_float4(mp[0], mp[1], mp[2], mp[3]);
-        *reinterpret_cast<float4 *>(o + SA_NPTS - k0 - 4) = make_float4(mp[4], mp[3], mp[2], mp[1]);
-        *reinterpret_cast<float4 *>(o + SA_MC + k0) = make_float4(mq[0], mq[1], mq[2], mq[3]);
-        *reinterpret_cast<float4 *>(o + SA_MC - k0 - 4) = make_float4(mq[4], mq[3], mq[2], mq[1]);
-    } else if constexpr (OUT == SA_OUT_MAG_HALF) {
-        float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);     // rows are not 16-byte aligned
+        if constexpr (OUT == SA_OUT_MAG_FULL) {
+            float *o = reinterpret_cast<float *>(out) + (size_t)f * SA_NPTS;
+            *reinterpret_cast<float4 *>(o + k0) = make_float4(mp[0], mp[1], mp[2], mp[3]);
+            *reinterpret_cast<float4 *>(o + SA_NPTS - k0 - 4) = make_float4(mp[4], mp[3], mp[2], mp[1]);
+            *reinterpret_cast<float4 *>(o + SA_MC + k0) = make_float4(mq[0], mq[1], mq[2], mq[3]);
+            *reinterpret_cast<float4 *>(o + SA_MC - k0 - 4) = make_float4(mq[4], mq[3], mq[2], mq[1]);
+        } else {
+            float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);     // rows are not 16-byte aligned
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[k0 + e] = cabs_fast(P[e]);
+            for (int e = 0; e < 4; ++e) o[k0 + e] = mp[e];
 #pragma unroll
-        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = cabs_fast(Q[e]);
-        if (k0 == 0) o[SA_MC] = cabs_fast(Q[0]);
+            for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = mq[e];
+            if (k0 == 0) o[SA_MC] = mq[0];
+        }
     } else {
         float2 *o = reinterpret_cast<float2 *>(out) + (size_t)f * (SA_MC + 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[k0 + e] = make_float2(P[e].x, P[e].y);
+        for (int e = 0; e < 4; ++e) o[k0 + e] = make_float2(R[e].x, I[e].x);
 #pragma unroll
-        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = make_float2(Q[e].x, -Q[e].y);
-        if (k0 == 0) o[SA_MC] = make_float2(Q[0].x, -Q[0].y);
+        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = make_float2(R[e].y, -I[e].y);
+        if (k0 == 0) o[SA_MC] = make_float2(R[0].y, -I[0].y);
     }
 }
 
@@ -517,10 +527,10 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
                 zm[4] = side[0];
             }
             if (r == 1 && q0 == 0) zm[0] = side[0];
-            cf P[5], Q[5];
+            cf R[5], I[5];
 #pragma unroll
-            for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], P[e], Q[e]);
-            split_store<OUT>(P, Q, out, f, k0);
+            for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], R[e], I[e]);
+            split_store<OUT>(R, I, out, f, k0);
         }
     }
     SA_STAMP(11);

@@ -63,9 +63,19 @@ __host__ __device__ __forceinline__ void bfly(cf &a, cf &b)
         b = a - t;
         a = a + t;
     } else if constexpr (M32 == 8) {          // W = -i : W*b = (b.y, -b.x)
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the swap and the negation are operand modifiers; left alone the compiler builds (b.y, -b.x)
+        // with a v_xor and a v_mov first
+        cf na, nb;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(na) : "v"(a), "v"(b));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(nb) : "v"(a), "v"(b));
+        a = na;
+        b = nb;
+#else
         const cf t = {b.y, -b.x};
         b = a - t;
         a = a + t;
+#endif
     } else {
         constexpr float wr = cos32(M32), wi = -sin32(M32);
         const cf wrr = {wr, wr};
@@ -105,9 +115,16 @@ __host__ __device__ __forceinline__ void fft_dit(cf (&a)[R])
 // complex product a * w as two packed ops
 __host__ __device__ __forceinline__ cf cmul(cf a, cf w)
 {
-    const cf wr = {w.x, w.x};
-    const cf wi = {-w.y, w.y};
-    return pk_fma(wi, swap_ri(a), wr * a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                 // a.x * (w.x, w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                        // + a.y * (-w.y, w.x)
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    const cf t = {a.x * w.x, a.x * w.y};
+    return {__builtin_fmaf(a.y, -w.y, t.x), __builtin_fmaf(a.y, w.x, t.y)};
+#endif
 }
 
 }  // namespace safft
