@@ -1,0 +1,112 @@
+// Micro-benchmark: what does the memory system give a kernel shaped like the fused chain -- one 64 KiB
+// frame in, one 64 KiB frame out per 256-thread workgroup, 35 KiB of LDS (4 workgroups per CU) -- when
+// there is no arithmetic at all?  Variants:
+//   0  plain grid-stride copy, 16 B per lane                      (the guide's "achievable copy" figure)
+//   1  frame per workgroup: 2 rounds of LDS-DMA in, LDS -> registers, 16-byte stores in frame order
+//   2  as 1, stores in the four streams of the split step (k, 16384-k-4, 8192+k, 8192-k-4)
+//   3  as 2, plus 64 KiB of table reads per frame from an L2-resident table (window + twiddles)
+// hipcc -O3 --offload-arch=gfx950 frame_stream.hip -o frame_stream && ./frame_stream [batch]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+constexpr int N = 16384;
+constexpr int kLds = 35616;
+
+__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n16)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                       const float4 *__restrict__ table, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int f = blockIdx.x;
+    if (f >= batch) return;
+    const float *xin = in + (size_t)f * N;
+    const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
+    float4 v[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = wave * 8 + i;
+            const float *src = xin + h * 8192 + n * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float4 q = lds4[g * 256 + t];
+            if (VAR == 3) {
+                const float4 w = table[(8 * h + g) * 256 + t];
+                q.x *= w.x; q.y *= w.y; q.z *= w.z; q.w *= w.w;
+            }
+            v[8 * h + g] = q;
+        }
+    }
+    float *o = out + (size_t)f * N;
+    if (VAR == 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) *reinterpret_cast<float4 *>(o + (g * 256 + t) * 4) = v[g];
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k0 = 4 * (t + 256 * (jj & 1)) + 2048 * (jj >> 1);
+            *reinterpret_cast<float4 *>(o + k0) = v[4 * jj + 0];
+            *reinterpret_cast<float4 *>(o + N - k0 - 4) = v[4 * jj + 1];
+            *reinterpret_cast<float4 *>(o + 8192 + k0) = v[4 * jj + 2];
+            *reinterpret_cast<float4 *>(o + 8192 - k0 - 4) = v[4 * jj + 3];
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int batch = argc > 1 ? atoi(argv[1]) : 4096;
+    const size_t bytes = (size_t)batch * N * 4;
+    float *in, *out;
+    float4 *table;
+    hipMalloc(&in, bytes);
+    hipMalloc(&out, bytes);
+    hipMalloc(&table, 16 * 256 * 16);
+    hipMemset(in, 0, bytes);
+    hipMemset(table, 0, 16 * 256 * 16);
+    hipFuncSetAttribute((const void *)frame_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipFuncSetAttribute((const void *)frame_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipFuncSetAttribute((const void *)frame_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const char *names[4] = {"grid-stride copy", "frame/WG, linear stores", "frame/WG, split-step store streams",
+                            "frame/WG, split stores + 64 KiB table reads"};
+    for (int pass = 0; pass < 2; ++pass)
+        for (int var = 0; var < 4; ++var) {
+            std::vector<float> ms;
+            for (int rep = 0; rep < 60; ++rep) {
+                hipEventRecord(e0);
+                if (var == 0) hipLaunchKernelGGL(copy_kernel, dim3(256 * 16), dim3(256), 0, 0, (const float4 *)in, (float4 *)out, bytes / 16);
+                if (var == 1) hipLaunchKernelGGL(frame_kernel<1>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
+                if (var == 2) hipLaunchKernelGGL(frame_kernel<2>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
+                if (var == 3) hipLaunchKernelGGL(frame_kernel<3>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float m;
+                hipEventElapsedTime(&m, e0, e1);
+                if (rep >= 20) ms.push_back(m);
+            }
+            std::sort(ms.begin(), ms.end());
+            const double med = ms[ms.size() / 2];
+            if (pass == 1)
+                printf("%-46s median %7.1f us  min %7.1f us  -> %6.2f TB/s (read+write)\n", names[var], med * 1e3, ms[0] * 1e3,
+                       2.0 * bytes / (med * 1e-3) / 1e12);
+        }
+    return 0;
+}
