@@ -154,6 +154,18 @@ template <bool PREDICT_NEXT, bool UNIT>
 __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float2 *__restrict__ mt_next,
                                             const float4 lanep, float2 *scr_s, int lane, int wave, v2f &z1, v2f &z2)
 {
+    // the next section's predictor taps: 64 wave-uniform floats, requested before the scan so that the
+    // four scalar loads are in flight across its barrier instead of being waited for one by one inside
+    // the recursion (the empty asm below pins them: "in SGPRs by here")
+    float m1n[32], m2n[32];
+    if constexpr (PREDICT_NEXT) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float2 mm = mt_next[j];
+            m1n[j] = mm.x;
+            m2n[j] = mm.y;
+        }
+    }
     // state after both chunks of this thread, from zero state: zT = Pc zA + zB
     float t1 = __builtin_fmaf(k.pc[0], z1.x, __builtin_fmaf(k.pc[1], z2.x, z1.y));
     float t2 = __builtin_fmaf(k.pc[2], z1.x, __builtin_fmaf(k.pc[3], z2.x, z2.y));
@@ -199,6 +211,13 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     v2f s1 = {a1s, b1s}, s2 = {a2s, b2s};
     const float b0 = k.c[0], b1 = k.c[1], b2 = k.c[2], na1 = -k.c[3], na2 = -k.c[4];
     v2f n1 = {0.f, 0.f}, n2 = {0.f, 0.f};
+    if constexpr (PREDICT_NEXT) {
+#pragma unroll
+        for (int j = 0; j < 32; j += 8)
+            asm volatile("" ::"s"(m1n[j]), "s"(m1n[j + 1]), "s"(m1n[j + 2]), "s"(m1n[j + 3]), "s"(m1n[j + 4]), "s"(m1n[j + 5]),
+                         "s"(m1n[j + 6]), "s"(m1n[j + 7]), "s"(m2n[j]), "s"(m2n[j + 1]), "s"(m2n[j + 2]), "s"(m2n[j + 3]),
+                         "s"(m2n[j + 4]), "s"(m2n[j + 5]), "s"(m2n[j + 6]), "s"(m2n[j + 7]));
+    }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const v2f x = d[j];
@@ -214,11 +233,10 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
         }
         d[j] = y;
         if constexpr (PREDICT_NEXT) {
-            // wave-uniform address: the taps arrive through scalar loads and feed the packed FMAs as
-            // SGPR operands (as LDS broadcasts they cost 40 % of the kernel's LDS cycles)
-            const float2 mm = mt_next[j];
-            n1 += mm.x * y;
-            n2 += mm.y * y;
+            // wave-uniform taps: SGPR operands of the packed FMAs (as LDS broadcasts they cost 40 % of
+            // the kernel's LDS cycles)
+            n1 += m1n[j] * y;
+            n2 += m2n[j] * y;
         }
     }
     z1 = n1;
