@@ -60,17 +60,57 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c)
 //   y = B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum
 //   taken modulo 2^16 (wrapping each term first gives the same residue).
 // The two subtracted terms use -floor(v/128) = floor((-v + 127)/128), so all five terms add.
+// The taps are held pre-shifted by 9: floor(c v / 128) mod 2^16 is then bits 16..31 of the 32-bit product
+// v * (c << 9) (exact: only bits above 31 are lost), i.e. its high word, which the SDWA form of v_add_u32
+// reads in place -- no shift instructions -- and whose last add sign-extends the 16-bit result on write.
+// 5 multiplies + 4 adds per step; the feedback path y[n-1] -> y[n] is two instructions long.
+__device__ __forceinline__ int mul_i24(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int add_hi_hi(int a, int b)          // hi16(a) + hi16(b)
+{
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
+        : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int add_acc_hi(int acc, int b)       // acc + hi16(b)
+{
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(r) : "v"(acc), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int add_acc_hi_sext16(int acc, int b)   // (int16)(acc + hi16(b))
+{
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(r) : "v"(acc), "v"(b));
+    return r;
+}
+
 struct BiqQ7 {
-    int cB0, cB1, cB2, nA0, nA1;            // nA* = -A*
+    int cB0, cB1, cB2, nA0, nA1;            // taps << 9; nA* = -A* << 9
     int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    __device__ __forceinline__ void set(int b0, int b1, int b2, int a0, int a1)
+    {
+        cB0 = b0 << 9; cB1 = b1 << 9; cB2 = b2 << 9; nA0 = -(a0 << 9); nA1 = -(a1 << 9);
+    }
     __device__ __forceinline__ int step(int x)
     {
-        const int p1 = mad_i24(x1, cB1, 0) >> 7;
-        const int p2 = mad_i24(x2, cB0, 0) >> 7;
-        const int p3 = mad_i24(y2, nA0, 127) >> 7;
-        const int p4 = mad_i24(y1, nA1, 127) >> 7;
-        const int p0 = mad_i24(x, cB2, 0) >> 7;
-        const int y = (int)(short)((p1 + p2 + p3) + (p4 + p0));
+        const int k127 = 127 << 9;
+        const int p1 = mul_i24(x1, cB1);
+        const int p2 = mul_i24(x2, cB0);
+        const int p3 = mad_i24(y2, nA0, k127);
+        const int p0 = mul_i24(x, cB2);
+        const int p4 = mad_i24(y1, nA1, k127);
+        int s = add_hi_hi(p1, p2);
+        s = add_acc_hi(s, p3);
+        s = add_acc_hi(s, p0);
+        const int y = add_acc_hi_sext16(s, p4);
         x2 = x1; x1 = x;
         y2 = y1; y1 = y;
         return y;
@@ -172,7 +212,9 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
 // The neighbour hand-off is a DPP row shift whose out-of-row case (lane 0 = section 0) keeps the `old`
 // operand, which holds the next input sample: no select.  Section 0 takes its inputs eight at a time
 // from LDS, so no LDS latency sits on the serial chain.  With 4096 frames that is 1024 waves, one per
-// SIMD of the chip; the chain is serial in time, so lanes, not waves, are what is left idle.
+// SIMD of the chip; the chain is serial in time, so lanes, not waves, are what is left idle.  (Two frames per
+// wave -- twice the waves, half of each idle -- measured 1.3x slower: a single wave already issues one
+// dependent instruction per ~7 cycles, two waves per SIMD reach ~4.7, but each carries half the frames.)
 template <bool WIDE>
 __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restrict__ in,
                                                          int16_t *__restrict__ out, int batch, SaQ15Params prm,
@@ -211,9 +253,9 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
     } else {
         if (sec < nreal) {
             const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
-            bq.cB0 = c[0]; bq.cB1 = c[1]; bq.cB2 = c[2]; bq.nA0 = -(int)c[3]; bq.nA1 = -(int)c[4];
+            bq.set(c[0], c[1], c[2], c[3], c[4]);
         } else {
-            bq.cB2 = 128; bq.cB0 = bq.cB1 = bq.nA0 = bq.nA1 = 0;   // (128 x) >> 7 = x exactly
+            bq.set(0, 0, 128, 0, 0);                         // (128 x) >> 7 = x exactly
         }
     }
     constexpr int kOutLane = 8;
