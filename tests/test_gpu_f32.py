@@ -120,6 +120,33 @@ def test_other_filter_families(ch, torch_mod, oracle, kind, ft, order):
     assert rel_maxnorm(got, mag) <= TOL
 
 
+def test_long_memory_filter_uses_every_scan_level(ch, torch_mod, oracle):
+    """A narrow low-pass (poles at radius ~0.996) keeps a state alive for thousands of samples: no scan level
+    may be skipped and the second-level scan over the 16 rows runs.  Checked against the float64 oracle; the
+    bound is the error a *sequential* float32 sosfilt makes on the same input (such poles amplify rounding)."""
+    from scipy import signal
+    from test_host_logic import _parse_plan
+    from fpga_real_time_fft_analyzer_amd.chain import iir_plan_from_sos
+    sos = signal.butter(4, 0.002, output="sos")
+    _, secs, _, _ = _parse_plan(iir_plan_from_sos(sos))
+    assert all(int(np.asarray(secs[i][0][5:6]).view(np.int32)[0]) == 0 for i in range(2))     # nothing skipped
+    rng = np.random.default_rng(5)
+    n = np.arange(N)
+    x = (0.5 * np.sin(2 * np.pi * 0.0004 * n)[None, :] + 0.1 * rng.standard_normal((3, N))).astype(np.float32)
+    y64, X, mag = oracle.chain_fp(x, sos)
+    ch.load_sos(sos)
+    ch.set_filter_mode(0xA1)
+    got_t = ch.process_f32(_dev(torch_mod, x), out_kind="time").cpu().numpy()
+    got_m = ch.process_f32(_dev(torch_mod, x)).cpu().numpy()
+    # sequential float32 reference of the same recurrence
+    hann = oracle.hann_f64().astype(np.float32)
+    seq = np.stack([oracle.sosfilt_f32_c(sos, row) for row in (x * hann).astype(np.float32)])
+    seq_err = np.abs(seq - y64).max() / np.abs(y64).max()
+    err_t = np.abs(got_t - y64).max() / np.abs(y64).max()
+    assert err_t <= max(1e-5, 4 * seq_err), (err_t, seq_err)
+    assert rel_maxnorm(got_m, mag) <= max(TOL, 4 * seq_err)
+
+
 def test_default_mode_is_the_rtl_taps_as_reals(ch, torch_mod, oracle):
     """Filter 0x00 on the float path = ALPHA/BETA taps /128 (imp/filter_pkg.vhd:54-68), 3x each."""
     a = [14 / 128, 0, -14 / 128, 1, 21 / 128, 107 / 128]
