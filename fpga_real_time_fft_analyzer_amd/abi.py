@@ -50,6 +50,14 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or "
             f"`make -C {CSRC}`).  This package has no CPU fallback.")
+    # torch first: its wheel bundles a HIP runtime under the same SONAME (libamdhip64.so.7) but another file
+    # name, so if this library is mapped first the process ends up with two runtimes and the second one to
+    # initialise sees no device.  With torch's copy already mapped, the loader binds this library to it and
+    # the tensors and the kernels share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     L.sa_create.argtypes = [C.c_int, C.POINTER(H)]

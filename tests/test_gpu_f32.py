@@ -3,6 +3,8 @@
 Gate: max-norm relative error per frame <= 1e-5 on the spectrum (the output of the
 path) against scipy.signal.sosfilt + numpy.fft.rfft evaluated in float64 on the same float32 inputs.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -41,6 +43,19 @@ def test_native_library_is_loaded(ch):
     """The HIP path is the one that runs: the in-tree .so is mapped into this process."""
     maps = open("/proc/self/maps").read()
     assert "libspecan_hip.so" in maps
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() maps the library before anything imported torch; smoke() must still find the
+    GPU (torch's wheel bundles its own HIP runtime: two runtimes in one process see no device)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g; from fpga_real_time_fft_analyzer_amd import abi; "
+            "assert abi.lib().sa_abi_version() == 1; g.smoke()")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "smoke ok" in r.stdout
 
 
 def test_config1_tone_full_chain(ch, torch_mod, oracle):
