@@ -208,7 +208,9 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     const float a2s = __builtin_fmaf(lanep.z, c1, __builtin_fmaf(lanep.w, c2, e2));
     const float b1s = __builtin_fmaf(k.pc[0], a1s, __builtin_fmaf(k.pc[1], a2s, z1.x));
     const float b2s = __builtin_fmaf(k.pc[2], a1s, __builtin_fmaf(k.pc[3], a2s, z2.x));
-    v2f s1 = {a1s, b1s}, s2 = {a2s, b2s};
+    // pole coordinates -> DF2T states of the recursion (sa_common.hpp)
+    const v2f q1 = {a1s, b1s}, q2 = {a2s, b2s};
+    v2f s1 = k.mback[0] * q1 + k.mback[1] * q2, s2 = k.mback[2] * q1 + k.mback[3] * q2;
     const float b0 = k.c[0], b1 = k.c[1], b2 = k.c[2], na1 = -k.c[3], na2 = -k.c[4];
     v2f n1 = {0.f, 0.f}, n2 = {0.f, 0.f};
     if constexpr (PREDICT_NEXT) {

@@ -19,11 +19,19 @@
 // resolution (|entries| < 1e-10: its contribution is < 1e-10 of the state); bit 4 set = the same holds
 // for Prow, so the start state of a row is just the previous row's total (no scan over the rows).
 #define SA_IIR_SKIP_ROWSCAN 16
+// State coordinates.  Everything between the predictor taps and the start states (taps m, Pc, plev, prow,
+// the per-lane table) lives in the section's *pole coordinates* z' = T z: T A T^-1 is a scaled rotation for a
+// complex pole pair and diagonal for two distinct real poles, so its powers never exceed |pole|^k.  In the
+// DF2T coordinates the powers of A = [[-a1,1],[-a2,0]] grow to ~1/angle for poles close to the real axis and
+// the float32 scan then loses up to 30x against a sequential evaluation (measured).
+// mback = T^-1 (row-major) takes the two start states back to DF2T right before the recursion.  It is the
+// identity for first-order, repeated-pole and padding sections.
 struct SaIirSecK {
     float c[5];            // b0,b1,b2,a1,a2
     int flags;
     float pad[2];
     float pc[4];           // Pc, row-major p00,p01,p10,p11
+    float mback[4];        // T^-1
     float plev[4][4];      // P2^(1,2,4,8)      in-row scan (DPP row_shr 1,2,4,8)
     float prow[4][4];      // Prow^(1,2,4,8)    scan over the 16 rows of a frame
 };

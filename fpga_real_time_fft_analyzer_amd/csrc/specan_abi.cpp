@@ -94,8 +94,33 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
         SaIirSecK &sp = plan->sec[s];
         sp.c[0] = (float)b0; sp.c[1] = (float)b1; sp.c[2] = (float)b2; sp.c[3] = (float)a1; sp.c[4] = (float)a2;
-        const Mat2 A = {-a1, 1.0, -a2, 0.0};
-        double v0 = b1 - a1 * b0, v1 = b2 - a2 * b0;      // Bv
+        // pole coordinates (sa_common.hpp): M = T^-1 has the eigen-directions (1, a1 + lambda) as unit columns
+        // -- real and imaginary part for a complex pair -- and An = T A M is what the scan works with
+        const Mat2 A0 = {-a1, 1.0, -a2, 0.0};
+        Mat2 M = {1, 0, 0, 1};
+        const double disc = a1 * a1 - 4.0 * a2;
+        if (a2 != 0.0 && disc != 0.0) {
+            double c0[2], c1[2];
+            if (disc < 0.0) {
+                c0[0] = 1.0; c0[1] = 0.5 * a1;                 // Re (1, a1 + lambda), lambda = -a1/2 + i sqrt(-disc)/2
+                c1[0] = 0.0; c1[1] = 0.5 * std::sqrt(-disc);   // Im
+            } else {
+                const double sq = std::sqrt(disc);
+                c0[0] = 1.0; c0[1] = a1 + 0.5 * (-a1 + sq);
+                c1[0] = 1.0; c1[1] = a1 + 0.5 * (-a1 - sq);
+            }
+            const double n0 = std::hypot(c0[0], c0[1]), n1 = std::hypot(c1[0], c1[1]);
+            const Mat2 cand = {c0[0] / n0, c1[0] / n1, c0[1] / n0, c1[1] / n1};
+            const double det = cand.a * cand.d - cand.b * cand.c;
+            // unit columns: |det| = sine of the angle between them; below 1e-6 the pair is numerically defective
+            if (std::isfinite(det) && std::fabs(det) > 1e-6) M = cand;
+        }
+        const double detM = M.a * M.d - M.b * M.c;
+        const Mat2 T = {M.d / detM, -M.b / detM, -M.c / detM, M.a / detM};
+        const Mat2 A = mul(T, mul(A0, M));
+        put(sp.mback, M);
+        double v0 = T.a * (b1 - a1 * b0) + T.b * (b2 - a2 * b0);      // T Bv
+        double v1 = T.c * (b1 - a1 * b0) + T.d * (b2 - a2 * b0);
         for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[j] = A^(31-j) Bv
             lt->m[s][j][0] = (float)v0;
             lt->m[s][j][1] = (float)v1;

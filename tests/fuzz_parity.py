@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the float chain against the float64 oracle (test infrastructure, GPU box).
+Random filter families / orders / cut-offs and hand-made degenerate cascades, random inputs.  Used by
+tests/test_gpu_f32.py::test_random_designs and runnable by hand: python tests/fuzz_parity.py SEED NCASES
+prints the worst max-norm relative error of the spectrum and every case above 1e-5."""
+import os
+import sys
+
+import numpy as np
+import torch
+from scipy import signal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+N = 16384
+
+
+def random_sos(rng):
+    kind = rng.choice(["butter", "cheby1", "cheby2", "ellip", "bessel", "hand"])
+    if kind == "hand":
+        rows = []
+        for _ in range(int(rng.integers(1, 7))):
+            r, th = rng.uniform(0.1, 0.97), rng.uniform(0.05, 3.0)
+            a1, a2 = -2 * r * np.cos(th), r * r
+            b = rng.choice([0, 1, 2, 3])
+            num = [[rng.normal(), rng.normal(), rng.normal()], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0],
+                   [-0.3, 0.0, -0.3]][b]
+            rows.append(num + [1.0, a1, a2])
+        return np.array(rows), "hand"
+    ft = rng.choice(["lowpass", "highpass", "bandpass", "bandstop"])
+    order = int(rng.integers(1, 13))
+    if ft in ("bandpass", "bandstop"):
+        order = max(1, order // 2)
+        lo = rng.uniform(0.02, 0.6)
+        wn = [lo, min(0.95, lo + rng.uniform(0.05, 0.3))]
+    else:
+        wn = rng.uniform(0.01, 0.9)
+    if kind == "butter":
+        sos = signal.butter(order, wn, btype=ft, output="sos")
+    elif kind == "cheby1":
+        sos = signal.cheby1(order, rng.uniform(0.1, 3), wn, btype=ft, output="sos")
+    elif kind == "cheby2":
+        sos = signal.cheby2(order, rng.uniform(20, 80), wn, btype=ft, output="sos")
+    elif kind == "ellip":
+        sos = signal.ellip(order, rng.uniform(0.1, 3), rng.uniform(20, 80), wn, btype=ft, output="sos")
+    else:
+        sos = signal.bessel(order, wn, btype=ft, output="sos", norm="phase")
+    return sos[:6], f"{kind}/{ft}/{order}"
+
+
+def sweep(ch, seed, ncases, verbose=False):
+    """Returns a list of (err, output/input peak ratio, sequential-float32 time-series err, label), one per
+    case: err = max-norm relative error of the magnitude spectrum against the float64 oracle."""
+    rng = np.random.default_rng(seed)
+    hann64 = orc.hann_f64()
+    hann = hann64.astype(np.float32)
+    ch.set_filter_mode(0xA1)
+    out = []
+    for case in range(ncases):
+        sos, label = random_sos(rng)
+        n = np.arange(N)
+        x = (rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.001, 0.49, (3, 1)) * n)
+             + rng.uniform(0.0, 0.2) * rng.standard_normal((3, N))).astype(np.float32)
+        y64, X, mag = orc.chain_fp(x, sos)
+        ch.load_sos(sos)
+        got = ch.process_f32(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.isfinite(got).all(), f"case {case} {label}: non-finite output"
+        den = np.abs(mag).max(axis=1)
+        err = float((np.abs(got - mag).max(axis=1) / np.where(den > 0, den, 1.0)).max())
+        # what a sequential float32 sosfilt achieves on the same input, and how far below the windowed input
+        # the output sits: rounding scales with the input, the norm with the output
+        seq = np.stack([orc.sosfilt_f32_c(sos / sos[:, 3:4], r) for r in (x * hann).astype(np.float32)])
+        seq_err = float(np.abs(seq - y64).max() / max(np.abs(y64).max(), 1e-30))
+        xin = np.abs(np.fft.rfft(x.astype(np.float64) * hann64, axis=1)).max(axis=1)
+        att = float((den / xin).min())
+        out.append((err, att, seq_err, label))
+        if verbose and err > max(1e-5, 4 * seq_err):
+            print(f"case {case} {label} nsec={len(sos)}: err {err:.2e} output/input peak {att:.1e} "
+                  f"(sequential f32 time-series err {seq_err:.2e})")
+    return out
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+    res = sweep(SpectrumChain(0), seed, ncases, verbose=True)
+    over = [r for r in res if r[0] > 1e-5]
+    bad = [r for r in over if r[0] > 4 * r[2]]
+    print(f"{ncases} cases, worst spectrum err {max(r[0] for r in res):.2e}, {len(over)} above 1e-5, "
+          f"{len(bad)} above max(1e-5, 4 x sequential-f32); of those above 1e-5 the largest output/input peak "
+          f"ratio is {max([r[1] for r in over], default=0):.1e}")
+    for err, att, seq_err, label in sorted(over, reverse=True)[:12]:
+        print(f"   err {err:.2e}  output/input peak {att:.1e}  sequential-f32 {seq_err:.2e}  {label}")
+
+
+if __name__ == "__main__":
+    main()

@@ -120,8 +120,9 @@ def test_pack_frame_is_little_endian(hip_lib_built):
 
 # ---- IIR plan algebra: emulate the kernel's predict / scan / recurse in float32 on the CPU
 def _parse_plan(plan):
-    """Flat view written by sa_iir_plan_from_sos: SaIirK (nsec, pad[3], 6 x {c[8], pc[4], plev[4][4],
-    prow[4][4]}) followed by SaIirLaneTab {m[6][32][2], p[6][16][4]}."""
+    """Flat view written by sa_iir_plan_from_sos: SaIirK (nsec, unit, gain, pad, 6 x {c[8], pc[4], mback[4],
+    plev[4][4], prow[4][4]}) followed by SaIirLaneTab {m[6][32][2], p[6][16][4]}.  Taps and matrices are in
+    the section's pole coordinates; mback takes a state back to DF2T."""
     nsec = int(plan[:1].view(np.int32)[0])
     unit = int(plan[1:2].view(np.int32)[0])
     gain = float(plan[2]) if unit else 1.0
@@ -129,9 +130,10 @@ def _parse_plan(plan):
     for _ in range(6):
         c = plan[off:off + 8]; off += 8        # b0,b1,b2,a1,a2, flags (int), pad, pad
         pc = plan[off:off + 4]; off += 4
+        mback = plan[off:off + 4]; off += 4
         plev = plan[off:off + 16].reshape(4, 4); off += 16
         prow = plan[off:off + 16].reshape(4, 4); off += 16
-        secs.append([c, pc, plev, prow, None])
+        secs.append([c, pc, plev, prow, None, mback])
     mt = plan[off:off + 6 * 64].reshape(6, 32, 2); off += 6 * 64
     for i in range(6):
         secs[i][4] = mt[i]
@@ -160,7 +162,7 @@ def emulate_chunked_iir(plan, x):
     nsec, secs, lt, gain = _parse_plan(plan)
     v = (x.astype(f) * gain).astype(f).reshape(256, 2, 32).copy()   # unit form: cascade gain folded into the window              # [thread][chunk][j]
     for s in range(nsec):
-        c, pc, plev, prow, m = secs[s]
+        c, pc, plev, prow, m, mb = secs[s]
         z = np.zeros((256, 2, 2), f)                         # [thread][chunk][state]
         for j in range(32):
             z[:, :, 0] += m[j, 0] * v[:, :, j]
@@ -180,6 +182,8 @@ def emulate_chunked_iir(plan, x):
                       axis=-1).astype(f).reshape(256, 2)
         sB = np.stack([pc[0] * sA[:, 0] + pc[1] * sA[:, 1] + zA[:, 0],
                        pc[2] * sA[:, 0] + pc[3] * sA[:, 1] + zA[:, 1]], axis=-1).astype(f)
+        back = lambda q: np.stack([mb[0] * q[:, 0] + mb[1] * q[:, 1], mb[2] * q[:, 0] + mb[3] * q[:, 1]], axis=-1).astype(f)
+        sA, sB = back(sA), back(sB)                           # pole coordinates -> DF2T states
         s1 = np.stack([sA[:, 0], sB[:, 0]], axis=1)           # [thread][chunk]
         s2 = np.stack([sA[:, 1], sB[:, 1]], axis=1)
         b0, b1, b2, a1, a2 = c[:5]
@@ -192,13 +196,37 @@ def emulate_chunked_iir(plan, x):
     return v.reshape(-1)
 
 
+def test_scan_in_pole_coordinates_keeps_sequential_accuracy(hip_lib_built, oracle):
+    """Poles close to the real axis (pole angle 0.008 rad here) make the powers of the DF2T transition matrix
+    grow to ~1/angle; with the scan run in DF2T coordinates the float32 result of this cascade was 28x worse
+    than a sequential float32 sosfilt (1.6e-3 against 5.8e-5 of max|y|).  The plan keeps taps and scan
+    matrices in pole coordinates: the emulation of the kernel's algebra must stay within 3x of sequential."""
+    from scipy.signal import sosfilt
+    from fpga_real_time_fft_analyzer_amd.chain import iir_plan_from_sos
+    sos = np.array([[1.31712426e-03, -9.33410745e-04, 1.31712426e-03, 1.0, 1.91684936e+00, 9.20172522e-01],
+                    [1.0, -1.69525561e+00, 1.0, 1.0, -1.98349975e+00, 9.83634833e-01]])     # cheby2 band-stop, order 2
+    plan = iir_plan_from_sos(sos)
+    rng = np.random.default_rng(2)
+    n = np.arange(N)
+    x = (0.6 * np.sin(2 * np.pi * 0.0127 * n) + 0.1 * rng.standard_normal(N)).astype(np.float32)
+    xw = (x * oracle.hann_f64().astype(np.float32) * np.float32(0.5)).astype(np.float32)
+    ref = sosfilt(sos, xw.astype(np.float64))
+    seq = oracle.sosfilt_f32_c(sos, xw)
+    e_seq = np.abs(seq - ref).max() / np.abs(ref).max()
+    e_chunked = np.abs(emulate_chunked_iir(plan, xw) - ref).max() / np.abs(ref).max()
+    assert e_chunked <= 3 * e_seq, (e_chunked, e_seq)
+    # the back-transform is the identity for first-order and padding sections
+    _, secs, _, _ = _parse_plan(iir_plan_from_sos(np.array([[0.2, 0.2, 0.0, 1.0, -0.6, 0.0]])))
+    assert all(np.array_equal(sec[5], [1, 0, 0, 1]) for sec in secs[:2])
+
+
 def test_iir_plan_reproduces_sosfilt(hip_lib_built, oracle):
     from scipy.signal import sosfilt
     from fpga_real_time_fft_analyzer_amd.chain import iir_plan_from_sos
     g = load_golden("g3_fp32_frames.npz")
     sos = g["sos"]
     plan = iir_plan_from_sos(sos)
-    assert plan.size == 4 + 6 * (8 + 4 + 16 + 16 + 64) + 6 * 16 * 4
+    assert plan.size == 4 + 6 * (8 + 4 + 4 + 16 + 16 + 64) + 6 * 16 * 4
     hann = oracle.hann_f64()
     for i in range(2):
         xw = (g["x"][i].astype(np.float64) * hann).astype(np.float32)
