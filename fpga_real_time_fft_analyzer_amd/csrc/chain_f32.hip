@@ -91,6 +91,21 @@ __device__ __forceinline__ float mul_to(float a, float b)
     return r;
 }
 
+// Output stores are streaming: every byte is written once and not read by this launch.  Marked
+// nontemporal they do not displace the window / twiddle tables (and the other workgroups' input lines)
+// from L2: measured -9 % on the fused kernel and -19 % on the no-IIR kernel at B = 4096.
+typedef float f4nt __attribute__((ext_vector_type(4)));
+typedef float f2nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(float *p, float a, float b, float c, float d)
+{
+    __builtin_nontemporal_store(f4nt{a, b, c, d}, reinterpret_cast<f4nt *>(p));
+}
+__device__ __forceinline__ void store_nt(float2 *p, float a, float b)
+{
+    __builtin_nontemporal_store(f2nt{a, b}, reinterpret_cast<f2nt *>(p));
+}
+__device__ __forceinline__ void store_nt(float *p, float a) { __builtin_nontemporal_store(a, p); }
+
 // ---------------------------------------------------------------------------------------------
 // Stage-in for the IIR, two rounds.  Round h brings chunk h (32 samples = 128 B) of every thread:
 // the samples go HBM -> LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write), 1 KiB = 8 rows
@@ -319,25 +334,25 @@ __device__ __forceinline__ void split_store(const cf (&R)[5], const cf (&I)[5], 
         }
         if constexpr (OUT == SA_OUT_MAG_FULL) {
             float *o = reinterpret_cast<float *>(out) + (size_t)f * SA_NPTS;
-            *reinterpret_cast<float4 *>(o + k0) = make_float4(mp[0], mp[1], mp[2], mp[3]);
-            *reinterpret_cast<float4 *>(o + SA_NPTS - k0 - 4) = make_float4(mp[4], mp[3], mp[2], mp[1]);
-            *reinterpret_cast<float4 *>(o + SA_MC + k0) = make_float4(mq[0], mq[1], mq[2], mq[3]);
-            *reinterpret_cast<float4 *>(o + SA_MC - k0 - 4) = make_float4(mq[4], mq[3], mq[2], mq[1]);
+            store_nt(o + k0, mp[0], mp[1], mp[2], mp[3]);
+            store_nt(o + SA_NPTS - k0 - 4, mp[4], mp[3], mp[2], mp[1]);
+            store_nt(o + SA_MC + k0, mq[0], mq[1], mq[2], mq[3]);
+            store_nt(o + SA_MC - k0 - 4, mq[4], mq[3], mq[2], mq[1]);
         } else {
             float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);     // rows are not 16-byte aligned
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[k0 + e] = mp[e];
+            for (int e = 0; e < 4; ++e) store_nt(o + k0 + e, mp[e]);
 #pragma unroll
-            for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = mq[e];
-            if (k0 == 0) o[SA_MC] = mq[0];
+            for (int e = 1; e < 5; ++e) store_nt(o + SA_MC - k0 - e, mq[e]);
+            if (k0 == 0) store_nt(o + SA_MC, mq[0]);
         }
     } else {
         float2 *o = reinterpret_cast<float2 *>(out) + (size_t)f * (SA_MC + 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[k0 + e] = make_float2(R[e].x, I[e].x);
+        for (int e = 0; e < 4; ++e) store_nt(o + k0 + e, R[e].x, I[e].x);
 #pragma unroll
-        for (int e = 1; e < 5; ++e) o[SA_MC - k0 - e] = make_float2(R[e].y, -I[e].y);
-        if (k0 == 0) o[SA_MC] = make_float2(R[0].y, -I[0].y);
+        for (int e = 1; e < 5; ++e) store_nt(o + SA_MC - k0 - e, R[e].y, -I[e].y);
+        if (k0 == 0) store_nt(o + SA_MC, R[0].y, -I[0].y);
     }
 }
 
@@ -577,11 +592,11 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
     stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
-    float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)f * SA_NPTS + 64 * t);
+    float *o4 = out + (size_t)f * SA_NPTS + 64 * t;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)
-        o4[g] = make_float4(2.f * d[4 * g].x, 2.f * d[4 * g + 1].x, 2.f * d[4 * g + 2].x, 2.f * d[4 * g + 3].x);
-        o4[g + 8] = make_float4(2.f * d[4 * g].y, 2.f * d[4 * g + 1].y, 2.f * d[4 * g + 2].y, 2.f * d[4 * g + 3].y);
+        store_nt(o4 + 4 * g, 2.f * d[4 * g].x, 2.f * d[4 * g + 1].x, 2.f * d[4 * g + 2].x, 2.f * d[4 * g + 3].x);
+        store_nt(o4 + 4 * (g + 8), 2.f * d[4 * g].y, 2.f * d[4 * g + 1].y, 2.f * d[4 * g + 2].y, 2.f * d[4 * g + 3].y);
     }
 }
 

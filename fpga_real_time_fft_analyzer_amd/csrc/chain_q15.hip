@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
             unsigned o[4];
             fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], 0u, 0u, 0u, true, o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o32[t + 256 * (u + 16 * i)] = o[i];
+            for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(o[i], o32 + t + 256 * (u + 16 * i));   // streaming: written once
         }
     }
 }
