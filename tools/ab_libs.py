@@ -19,6 +19,11 @@ n = torch.arange(16384, device="cuda", dtype=torch.float32)
 fb = torch.rand(B, 1, generator=gen, device="cuda") * 0.44 + 0.01
 x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, 16384, generator=gen, device="cuda")).contiguous()
 out = torch.empty_like(x)
+# ROT buffer pairs used round-robin in the timed loops: one pair (256 MiB in) would sit in the 256 MB Infinity
+# Cache from launch to launch and the comparison would be about the cache, not HBM
+ROT = int(os.environ.get("SA_ROT", "4"))
+xs = [x] + [x.clone() for _ in range(ROT - 1)]
+outs = [out] + [torch.empty_like(x) for _ in range(ROT - 1)]
 libs = []
 for name in sys.argv[1:]:
     L = C.CDLL(os.path.join(PKG, name))
@@ -54,8 +59,8 @@ for mode in (0xA1, 0xB1):
                     d = (out - ref).abs().max().item() / ref.abs().max().item()
                     print(f"   {name} vs {order[0][0]} mode 0x{mode:02X}: max rel diff {d:.2e}")
             t0 = time.perf_counter()
-            for _ in range(REPS):
-                L.sa_process_f32(h, x.data_ptr(), out.data_ptr(), B, 0, st)
+            for i in range(REPS):
+                L.sa_process_f32(h, xs[i % ROT].data_ptr(), outs[i % ROT].data_ptr(), B, 0, st)
             torch.cuda.synchronize()
             res.setdefault(name, []).append((time.perf_counter() - t0) / REPS)
     for name, _, _ in libs:

@@ -5,6 +5,8 @@
 //   1  frame per workgroup: 2 rounds of LDS-DMA in, LDS -> registers, 16-byte stores in frame order
 //   2  as 1, stores in the four streams of the split step (k, 16384-k-4, 8192+k, 8192-k-4)
 //   3  as 2, plus 64 KiB of table reads per frame from an L2-resident table (window + twiddles)
+//   4  grid-stride copy with nontemporal stores          5  as 2 with nontemporal stores
+//   6  as 3 with nontemporal stores                      7  as 5 with nontemporal (streaming) DMA loads too
 // hipcc -O3 --offload-arch=gfx950 frame_stream.hip -o frame_stream && ./frame_stream [batch]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,12 +17,25 @@
 constexpr int N = 16384;
 constexpr int kLds = 35616;
 
-__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n16)
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_kernel(const f4v *__restrict__ in, f4v *__restrict__ out, size_t n16)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        if (NT) __builtin_nontemporal_store(in[i], out + i);
+        else out[i] = in[i];
+    }
 }
 
-template <int VAR>
+template <bool NT>
+__device__ __forceinline__ void st16(float *p, float4 v)
+{
+    if (NT) __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+
+template <int VAR, bool NT, int AUX>
 __global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                        const float4 *__restrict__ table, int batch)
 {
@@ -39,7 +54,7 @@ __global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__
             const int n = wave * 8 + i;
             const float *src = xin + h * 8192 + n * 256 + lane * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, AUX);
         }
         __syncthreads();
 #pragma unroll
@@ -55,15 +70,15 @@ __global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__
     float *o = out + (size_t)f * N;
     if (VAR == 1) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) *reinterpret_cast<float4 *>(o + (g * 256 + t) * 4) = v[g];
+        for (int g = 0; g < 16; ++g) st16<NT>(o + (g * 256 + t) * 4, v[g]);
     } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int k0 = 4 * (t + 256 * (jj & 1)) + 2048 * (jj >> 1);
-            *reinterpret_cast<float4 *>(o + k0) = v[4 * jj + 0];
-            *reinterpret_cast<float4 *>(o + N - k0 - 4) = v[4 * jj + 1];
-            *reinterpret_cast<float4 *>(o + 8192 + k0) = v[4 * jj + 2];
-            *reinterpret_cast<float4 *>(o + 8192 - k0 - 4) = v[4 * jj + 3];
+            st16<NT>(o + k0, v[4 * jj + 0]);
+            st16<NT>(o + N - k0 - 4, v[4 * jj + 1]);
+            st16<NT>(o + 8192 + k0, v[4 * jj + 2]);
+            st16<NT>(o + 8192 - k0 - 4, v[4 * jj + 3]);
         }
     }
 }
@@ -72,30 +87,46 @@ int main(int argc, char **argv)
 {
     const int batch = argc > 1 ? atoi(argv[1]) : 4096;
     const size_t bytes = (size_t)batch * N * 4;
-    float *in, *out;
+    // ROT input and output buffers used round-robin: with one pair the 256 MiB input of a 4096-frame batch
+    // stays in the 256 MB Infinity Cache from one launch to the next (streaming stores do not displace it)
+    // and the "HBM" figure becomes a cache figure.  frame_stream [batch] [rot]
+    const int ROT = argc > 2 ? atoi(argv[2]) : 1;
+    std::vector<float *> ins(ROT), outs(ROT);
+    for (int r = 0; r < ROT; ++r) {
+        hipMalloc(&ins[r], bytes);
+        hipMalloc(&outs[r], bytes);
+        hipMemset(ins[r], 0, bytes);
+    }
+    float *in = ins[0], *out = outs[0];
     float4 *table;
-    hipMalloc(&in, bytes);
-    hipMalloc(&out, bytes);
     hipMalloc(&table, 16 * 256 * 16);
-    hipMemset(in, 0, bytes);
     hipMemset(table, 0, 16 * 256 * 16);
-    hipFuncSetAttribute((const void *)frame_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    hipFuncSetAttribute((const void *)frame_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    hipFuncSetAttribute((const void *)frame_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    auto k1 = frame_kernel<1, false, 0>;
+    auto k2 = frame_kernel<2, false, 0>;
+    auto k3 = frame_kernel<3, false, 0>;
+    auto k5 = frame_kernel<2, true, 0>;
+    auto k6 = frame_kernel<3, true, 0>;
+    auto k7 = frame_kernel<2, true, 2>;
+    void (*ks[8])(const float *, float *, const float4 *, int) = {nullptr, k1, k2, k3, nullptr, k5, k6, k7};
+    for (int v = 0; v < 8; ++v)
+        if (ks[v]) hipFuncSetAttribute((const void *)ks[v], hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const char *names[4] = {"grid-stride copy", "frame/WG, linear stores", "frame/WG, split-step store streams",
-                            "frame/WG, split stores + 64 KiB table reads"};
+    const char *names[8] = {"grid-stride copy", "frame/WG, linear stores", "frame/WG, split-step store streams",
+                            "frame/WG, split stores + 64 KiB table reads", "grid-stride copy, nontemporal stores",
+                            "frame/WG, split stores, nontemporal", "frame/WG, split nt stores + 64 KiB table reads",
+                            "frame/WG, split nt stores, nt DMA loads"};
     for (int pass = 0; pass < 2; ++pass)
-        for (int var = 0; var < 4; ++var) {
+        for (int var = 0; var < 8; ++var) {
             std::vector<float> ms;
             for (int rep = 0; rep < 60; ++rep) {
+                in = ins[rep % ROT];
+                out = outs[rep % ROT];
                 hipEventRecord(e0);
-                if (var == 0) hipLaunchKernelGGL(copy_kernel, dim3(256 * 16), dim3(256), 0, 0, (const float4 *)in, (float4 *)out, bytes / 16);
-                if (var == 1) hipLaunchKernelGGL(frame_kernel<1>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
-                if (var == 2) hipLaunchKernelGGL(frame_kernel<2>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
-                if (var == 3) hipLaunchKernelGGL(frame_kernel<3>, dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
+                if (var == 0) hipLaunchKernelGGL(copy_kernel<false>, dim3(256 * 16), dim3(256), 0, 0, (const f4v *)in, (f4v *)out, bytes / 16);
+                else if (var == 4) hipLaunchKernelGGL(copy_kernel<true>, dim3(256 * 16), dim3(256), 0, 0, (const f4v *)in, (f4v *)out, bytes / 16);
+                else hipLaunchKernelGGL(ks[var], dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float m;
@@ -105,7 +136,7 @@ int main(int argc, char **argv)
             std::sort(ms.begin(), ms.end());
             const double med = ms[ms.size() / 2];
             if (pass == 1)
-                printf("%-46s median %7.1f us  min %7.1f us  -> %6.2f TB/s (read+write)\n", names[var], med * 1e3, ms[0] * 1e3,
+                printf("rot=%d %-48s median %7.1f us  min %7.1f us  -> %6.2f TB/s (read+write)\n", ROT, names[var], med * 1e3, ms[0] * 1e3,
                        2.0 * bytes / (med * 1e-3) / 1e12);
         }
     return 0;
