@@ -102,10 +102,12 @@ def main():
 
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; wraps around only when rehearsing N ranks on a box with fewer GPUs
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
-    ch = SpectrumChain(local_rank)                   # raises if the HIP extension is missing
+    ch = SpectrumChain(dev_index)                    # raises if the HIP extension is missing
     ch.load_sos(sos)
     ch.set_filter_mode(0xA1)
 
