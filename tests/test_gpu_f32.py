@@ -271,6 +271,27 @@ def test_full_size_properties(ch, torch_mod):
     assert np.abs(s[idx].cpu().numpy() - X).max(axis=1).max() <= TOL * np.abs(X).max()
 
 
+def test_batch_beyond_two_gib(ch, torch_mod):
+    """40 000 frames = 2.6 GB in and out: byte offsets pass 2^31 (BASELINE config 5 is 32 768 frames, sharded).
+    The last frames of the big batch must equal the same frames processed alone."""
+    torch = torch_mod
+    g = load_golden("g2_config1.npz")
+    ch.load_sos(g["sos"])
+    ch.set_filter_mode(0xA1)
+    B = 40000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty((B, N), dtype=torch.float32, device="cuda")
+    x.normal_(generator=gen)
+    out = ch.process_f32(x)
+    idx = torch.tensor([0, 1, 32767, 32768, B - 2, B - 1], device="cuda")
+    small = ch.process_f32(x[idx].contiguous())
+    assert torch.equal(out[idx], small)
+    assert torch.isfinite(out[::997]).all()
+    del out
+    m = ch.process_f32(x, out_kind="mag_half")
+    assert torch.equal(m[idx], ch.process_f32(x[idx].contiguous(), out_kind="mag_half"))
+
+
 def test_side_stream_and_graph_replay(ch, torch_mod, oracle):
     """Calls are asynchronous on the caller's stream and capturable into a HIP graph (no allocation,
     no synchronisation inside sa_process_f32 once the kernels have been used once)."""

@@ -169,6 +169,20 @@ def test_full_size_batch(ch, torch_mod, oracle):
     assert torch.equal(iq2, iq[perm])
 
 
+def test_batch_beyond_two_gib(ch, torch_mod):
+    """36 000 frames: the IQ output is 2.36 GB (offsets pass 2^31), the filter workspace 1.18 GB."""
+    torch = torch_mod
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    B = 36000
+    x = torch.randint(-2048, 2048, (B, N), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
+    idx = torch.tensor([0, 1, 16383, 16384, 32767, 32768, B - 1], device="cuda")
+    for cmd in (0x00, 0xB1):
+        ch.set_filter_mode(cmd)
+        iq = ch.process_q15(x)
+        assert torch.equal(iq[idx], ch.process_q15(x[idx].contiguous()))
+        del iq
+
+
 def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
     """N1/N2: the board as gui.py sees it -- command bytes in, frames / datagrams out."""
     from fpga_real_time_fft_analyzer_amd import designer, frames
