@@ -592,11 +592,33 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
     stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
-    float *o4 = out + (size_t)f * SA_NPTS + 64 * t;
+    // Stage-out, the stage-in run backwards: each thread owns 64 consecutive samples, so storing straight
+    // from the registers puts every lane of a store instruction into another 256-byte block (measured 5x
+    // slower than the whole spectrum chain).  Round h: the thread writes its chunk h into its 128-byte LDS row
+    // (same XOR swizzle as the stage-in), then every wave instruction picks up 1 KiB of LDS in linear order,
+    // i.e. eight 128-byte row segments, and stores them with 16 B per lane.
+    float4 *lds4 = reinterpret_cast<float4 *>(smem);
+    float *o = out + (size_t)f * SA_NPTS;
+    const int lane = t & 63, wave = t >> 6, rl = lane >> 3;
+    const int sw = (t >> 1) & 7;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {   // undo the folded 1/2 (exact)
-        store_nt(o4 + 4 * g, 2.f * d[4 * g].x, 2.f * d[4 * g + 1].x, 2.f * d[4 * g + 2].x, 2.f * d[4 * g + 3].x);
-        store_nt(o4 + 4 * (g + 8), 2.f * d[4 * g].y, 2.f * d[4 * g + 1].y, 2.f * d[4 * g + 2].y, 2.f * d[4 * g + 3].y);
+    for (int h = 0; h < 2; ++h) {
+        lds_barrier();                       // scan scratch / previous round consumed
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {        // undo the folded 1/2 (exact)
+            const float4 v = h == 0 ? make_float4(2.f * d[4 * g].x, 2.f * d[4 * g + 1].x, 2.f * d[4 * g + 2].x, 2.f * d[4 * g + 3].x)
+                                    : make_float4(2.f * d[4 * g].y, 2.f * d[4 * g + 1].y, 2.f * d[4 * g + 2].y, 2.f * d[4 * g + 3].y);
+            lds4[t * 8 + (g ^ sw)] = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = wave * 8 + i;                        // slab: rows 8n .. 8n+7
+            const int r = 8 * n + rl;
+            const int lc = (lane & 7) ^ ((r >> 1) & 7);
+            const float4 v = lds4[n * 64 + lane];
+            store_nt(o + r * 64 + h * 32 + lc * 4, v.x, v.y, v.z, v.w);
+        }
     }
 }
 
