@@ -304,7 +304,9 @@ __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -3
 // y = sat16((u * w) >> 15), truncation; e == 0 is an exact pass-through (SA-FXFFT-1)
 __device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool unity)
 {
-    if (unity) return pack2(sat16(ur), sat16(ui));
+    // (sum of four int16) >> 2 lies in [-32768, 32767] already: the saturation of the spec cannot trigger on a
+    // pass-through, only after a twiddle product (|u w| >> 15 reaches 65534)
+    if (unity) return pack2(ur, ui);
     const int wr = lo16(w), wi = hi16(w);
     const int pr = (ur * wr - ui * wi) >> 15;
     const int pi = (ur * wi + ui * wr) >> 15;
@@ -320,7 +322,7 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
     const int cr = lo16(c), ci = hi16(c), dr = lo16(d), di = hi16(d);
     const int sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;      // a +/- c
     const int ur = br + dr, ui = bi + di, vr = br - dr, vi = bi - di;      // b +/- d
-    o[0] = pack2(sat16((sr + ur) >> 2), sat16((si + ui) >> 2));
+    o[0] = pack2((sr + ur) >> 2, (si + ui) >> 2);                          // in range by construction, see fx_twiddle
     o[1] = fx_twiddle((tr + vi) >> 2, (ti - vr) >> 2, w1, unity);          // a - i b - c + i d
     o[2] = fx_twiddle((sr - ur) >> 2, (si - ui) >> 2, w2, unity);
     o[3] = fx_twiddle((tr - vi) >> 2, (ti + vr) >> 2, w3, unity);          // a + i b - c - i d
