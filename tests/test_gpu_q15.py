@@ -89,6 +89,24 @@ def test_extreme_inputs(ch, torch_mod, oracle):
     assert ch.process_q15(e).shape == (0, N, 2)
 
 
+def test_random_coefficient_uploads(ch, torch_mod, oracle):
+    """60 random 12-byte uploads (every int8 value allowed, including -128 and unstable feedback taps whose
+    outputs wrap around) on full-scale and 12-bit inputs: the window + cascade output and the IQ frame are
+    bit-exact against the integer model."""
+    rng = np.random.default_rng(2024)
+    ch.set_filter_mode(0xA1)
+    for case in range(60):
+        c12 = rng.integers(-128, 128, 12).astype(np.int8)
+        if case % 5 == 0:
+            c12[rng.integers(0, 12)] = -128
+        x = rng.integers(-32768, 32768, (3, N)).astype(np.int16)
+        x[1] = rng.integers(-2048, 2048, N)
+        ch.load_coeffs_q7(c12)
+        iq_ref, t_ref = oracle.chain_q15(x, None, 0, 0xA1, c12, None, want_time=True)
+        assert np.array_equal(ch.filter_q15(_dev(torch_mod, x)).cpu().numpy(), t_ref), (case, c12)
+        assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), iq_ref), (case, c12)
+
+
 def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
     rng = np.random.default_rng(99)
     x = rng.integers(-2048, 2048, size=(3, N)).astype(np.int16)
