@@ -107,6 +107,25 @@ def test_random_coefficient_uploads(ch, torch_mod, oracle):
         assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), iq_ref), (case, c12)
 
 
+def test_random_wide_cascades(ch, torch_mod, oracle):
+    """Wide mode (0xA2): random Q2.14 cascades of 1..6 sections, any int16 tap (saturating accumulators make
+    unstable ones well defined), both window modes, bit-exact against the integer model."""
+    rng = np.random.default_rng(77)
+    ch.set_filter_mode(0xA2)
+    for case in range(30):
+        nsec = int(rng.integers(1, 7))
+        sos = rng.integers(-32768, 32768, (nsec, 6)).astype(np.int16)
+        if case % 2:
+            sos = (sos // 4).astype(np.int16)                           # mostly stable-ish magnitudes as well
+        x = rng.integers(-32768, 32768, (2, N)).astype(np.int16)
+        wm = case % 2
+        ch.set_window_mode_q15(wm)
+        ch.load_sos_q14(sos)
+        ref = oracle.chain_q15(x, None, wm, 0xA2, None, sos)
+        assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), ref), (case, sos)
+    ch.set_window_mode_q15(0)
+
+
 def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
     rng = np.random.default_rng(99)
     x = rng.integers(-2048, 2048, size=(3, N)).astype(np.int16)
