@@ -6,7 +6,7 @@
 // Shape of the computation (DESIGN.md sections 3-5):
 //   * LDS holds HALF a frame at a time (35 KiB per workgroup) so that four workgroups share a CU
 //     (16 waves): every exchange is done in two index-split rounds.  The kernel is latency bound
-//     at lower occupancy (profiles/r1_b_phase_stamps.txt).
+//     at lower occupancy (profiles/r1_phase_stamps_iir.txt).
 //   * thread t owns samples [64t, 64t+64) for the IIR as two chunks of 32 held as float pairs
 //     (chunk A in .x, chunk B in .y) so the serial recursion runs on packed-fp32 instructions.
 //   * per section: the end state of every chunk from zero state is a dot product ("predict", fused
@@ -15,7 +15,9 @@
 //     then the exact DF2T recursion of scipy.signal.sosfilt runs from them.
 //   * the real FFT is an 8192-point complex FFT of z[m] = x[2m] + i x[2m+1] factored 32 x 16 x 16,
 //     each factor in registers (fft_regs.hpp), then the split step X[k] = Xe[k] + W_N^k Xo[k].
-//   * all 16384 magnitudes are written (upper half mirrored), one dword per lane, coalesced.
+//     Taps and scan matrices live in the section's pole coordinates (sa_common.hpp): float32 accuracy
+//     then matches a sequential evaluation also for poles next to the real axis.
+//   * all 16384 magnitudes are written (upper half mirrored) as aligned 16-byte nontemporal stores.
 // The factor 1/2 of the split step is folded into the window table (exact in binary fp).
 #include "sa_common.hpp"
 #include "fft_regs.hpp"
