@@ -9,6 +9,13 @@ data-path collective (weak scaling: 4096 frames per GPU); the only inter-rank tr
 timing barrier / max-reduce, done over gloo on the host.
 
 Prints ONE JSON line on rank 0 with the driver's keys plus ``roofline`` and ``cpu_baseline``.
+
+Two ways to get N ranks (one process per GPU, BASELINE.json configs[4]):
+  * under ``torch.distributed.run`` (WORLD_SIZE in the environment): this process IS one rank;
+  * plain ``python bench.py --gpus N``: this process becomes a launcher that starts N fresh rank
+    processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, seeds 10..10+N-1) before anything touches a GPU,
+    relays rank 0's JSON line and exits non-zero unless that line reports ``n_gpus == N``.
+A rank never re-executes itself; on failure it exits non-zero and the launcher stops the others.
 """
 from __future__ import annotations
 
@@ -74,6 +81,185 @@ def cpu_baseline(sos: np.ndarray) -> dict:
                       f"(64-frame slices), same synthetic distribution as the GPU run"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Launcher mode: start ``n`` rank processes of this script (one per GPU), relay rank 0's line.
+    Nothing here imports torch or touches a GPU.  Returns the exit code for the launcher."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc, deadline = "", 0, time.time() + float(os.environ.get("SA_BENCH_LAUNCH_TIMEOUT", "1500"))
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            if procs[r].poll() is not None:
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode or 1
+        if rc or time.time() > deadline:           # one rank failed (or hung): stop the others, by PID
+            for r in pending:
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            rc = rc or 124
+            break
+        if pending:
+            time.sleep(0.05)
+    if not out0 and procs[0].stdout and not procs[0].stdout.closed:
+        try:
+            out0 = procs[0].stdout.read()
+        except ValueError:
+            pass
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                continue
+    if rc:
+        print(f"bench.py launcher: a rank failed (exit code {rc})", file=sys.stderr)
+        return rc
+    if line is None or line.get("n_gpus") != n:
+        print(f"bench.py launcher: asked for {n} ranks, rank 0 reported {None if line is None else line.get('n_gpus')}",
+              file=sys.stderr)
+        return 3
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+class StubDevice:
+    """Control-plane rehearsal without a GPU (tests/test_sharding_gloo.py sets SA_BENCH_STUB=1): the device
+    step is a short sleep, everything else (rank set-up, barrier, MAX-reduce, JSON line) is the real code.
+    Its line says data = "stub" and carries no roofline; it is never a measurement."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        if os.environ.get("SA_BENCH_STUB_FAIL_RANK") == str(rank):     # failure-path rehearsal for the launcher test
+            sys.exit(7)
+
+    def step(self):
+        time.sleep(0.002 * (1 + self.rank))
+
+    def sync(self):
+        pass
+
+    def kernel_ms(self, steps):
+        return [2.0 * (1 + self.rank)] * steps
+
+    def close(self):
+        pass
+
+
+class GpuWorkload:
+    """One rank = one GPU, one handle, one stream; R rotating buffer pairs of B frames resident in HBM."""
+    kernel_name = "chain_f32_kernel<6 sections, unit numerators, MAG_FULL>"
+
+    def __init__(self, a, rank, local_rank, sos):
+        import torch
+        from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain
+        self.torch = torch
+        # one rank per GPU; wraps around only when rehearsing N ranks on a box with fewer GPUs
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        self.dev = dev = torch.device("cuda", dev_index)
+        self.ch = ch = SpectrumChain(dev_index)
+        ch.load_sos(sos)
+        ch.set_filter_mode(0xA1)
+        self.B = B = a.batch
+        self.gen = gen = torch.Generator(device=dev).manual_seed(10 + rank)
+        n = torch.arange(N, device=dev, dtype=torch.float32)
+        # R distinct batches and output buffers, step i works on pair i mod R.  With R = 1 the 256 MiB input of
+        # a 4096-frame batch survives in the 256 MB Infinity Cache between steps (the outputs are streaming
+        # stores and do not displace it) and the step runs ~10 % faster than HBM can feed it.
+        self.R = R = max(1, a.buffers)
+        self.xs, self.outs = [], []
+        for _ in range(R):
+            fb = torch.rand(B, 1, generator=gen, device=dev) * 0.44 + 0.01
+            self.xs.append((0.8 * torch.sin(2 * np.pi * fb * n)
+                            + 0.05 * torch.randn(B, N, generator=gen, device=dev)).contiguous())
+            self.outs.append(torch.empty((B, N), dtype=torch.float32, device=dev))
+        self.step_no = 0
+
+    def step(self):
+        i = self.step_no % self.R
+        self.step_no += 1
+        self.ch.process_f32(self.xs[i], out=self.outs[i])
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def kernel_ms(self, steps):
+        """HIP events around each launch, recorded on the stream the kernel is launched on (torch's current
+        stream of this device is the one handed to the C ABI)."""
+        torch = self.torch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for e0, e1 in evs:
+            e0.record()
+            self.step()
+            e1.record()
+        self.sync()
+        return [e0.elapsed_time(e1) for e0, e1 in evs]
+
+    def extras(self, steps):
+        """Bypass (config 2) and Q15 (config 4) figures next to the headline; not the bench line's value."""
+        torch, ch, dev, B, R, gen = self.torch, self.ch, self.dev, self.B, self.R, self.gen
+        out = {}
+
+        def time_it(fn, k):
+            for _ in range(3):
+                fn()
+            self.sync()
+            t = time.perf_counter()
+            for _ in range(k):
+                fn()
+            self.sync()
+            return (time.perf_counter() - t) / k
+        ch.set_filter_mode(0xB1)
+        x256 = self.xs[0][:256].contiguous()
+        o256 = self.outs[0][:256]
+        dt = time_it(lambda: ch.process_f32(x256, out=o256), 50)
+        out["config2_bypass_b256"] = {"frames_per_s": 256 / dt, "GBps": 256 * BYTES_PER_FRAME_F32 / dt / 1e9}
+        dt = time_it(self.step, steps)
+        out["bypass_b4096"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
+        ch.reserve(B)
+        for tag, lo, hi in (("", -2048, 2048), ("_fullscale", -32768, 32768)):
+            xqs = [torch.randint(lo, hi, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+                   for _ in range(R)]
+            oqs = [torch.empty((B, N, 2), dtype=torch.int16, device=dev) for _ in range(R)]
+            k = [0]
+
+            def qstep():
+                ch.process_q15(xqs[k[0] % R], out=oqs[k[0] % R])
+                k[0] += 1
+            for name, cmd in (("config4_q15_default_iir", 0x00), ("q15_bypass", 0xB1)):
+                ch.set_filter_mode(cmd)
+                dt = time_it(qstep, 5)
+                out[name + tag] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+            del xqs, oqs
+        ch.set_filter_mode(0xA1)
+        return out
+
+    def close(self):
+        self.ch.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,134 +272,87 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time the bypass (config 2) and Q15 (config 4) paths")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:                               # launcher mode: no GPU call has happened in this process
+            sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start one rank per GPU "
+              f"(--nproc-per-node {a.gpus}) or drop WORLD_SIZE and let bench.py start the ranks", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = os.environ.get("SA_BENCH_STUB") == "1"
     sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]    # 12th-order Butterworth, wn = 0.2
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
         cpu = cpu_baseline(sos)                      # before any GPU initialisation (forks)
 
     import torch
     import torch.distributed as dist
-    from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain
 
     if world > 1:
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    # one rank per GPU; wraps around only when rehearsing N ranks on a box with fewer GPUs
-    dev_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-
-    ch = SpectrumChain(dev_index)                    # raises if the HIP extension is missing
-    ch.load_sos(sos)
-    ch.set_filter_mode(0xA1)
-
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=600))
     B = a.batch
-    gen = torch.Generator(device=dev).manual_seed(10 + rank)
-    n = torch.arange(N, device=dev, dtype=torch.float32)
-    fb = torch.rand(B, 1, generator=gen, device=dev) * 0.44 + 0.01
-    x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, N, generator=gen, device=dev)).contiguous()
-    out = torch.empty((B, N), dtype=torch.float32, device=dev)
-    # R distinct batches and output buffers, step i works on pair i mod R.  With R = 1 the 256 MiB input of
-    # a 4096-frame batch survives in the 256 MB Infinity Cache between steps (the outputs are streaming
-    # stores and do not displace it) and the step runs ~10 % faster than HBM can feed it.
     R = max(1, a.buffers)
-    xs, outs = [x], [out]
-    for r in range(1, R):
-        fbr = torch.rand(B, 1, generator=gen, device=dev) * 0.44 + 0.01
-        xs.append((0.8 * torch.sin(2 * np.pi * fbr * n) + 0.05 * torch.randn(B, N, generator=gen, device=dev)).contiguous())
-        outs.append(torch.empty((B, N), dtype=torch.float32, device=dev))
-    step_no = [0]
-
-    def step():
-        i = step_no[0] % R
-        step_no[0] += 1
-        ch.process_f32(xs[i], out=outs[i])
+    if stub:
+        wl = StubDevice(rank)
+    else:
+        wl = GpuWorkload(a, rank, local_rank, sos)   # raises if the HIP extension is missing
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        wl.sync()
         if world > 1:
             dist.barrier()
 
     # Untimed pre-warm: the chip leaves its idle power state only after ~100 ms of sustained load (the
     # same launches measured 8-10 % slower in the first milliseconds).  Then the W contract warm-up steps.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.25:
+    while time.perf_counter() - t_pre < (0.0 if stub else 0.25):
         for _ in range(10):
-            step()
-        torch.cuda.synchronize(dev)
+            wl.step()
+        wl.sync()
     for _ in range(a.warmup):
-        step()
+        wl.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize(dev)
+        wl.step()
+    wl.sync()
     t1 = time.perf_counter()
     from bench_shard import aggregate_fps
     fps_total, elapsed = aggregate_fps(B, a.steps, t1 - t0, world)     # MAX over ranks (gloo, host side)
     if world > 1:
         dist.barrier()
 
-    # per-launch kernel time with HIP events on the launch stream (torch's current stream is the one
-    # handed to the ABI), median over the same number of steps
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
-    torch.cuda.synchronize(dev)
-    k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    # per-launch kernel time with HIP events on the launch stream, same number of steps
+    k_ms = sorted(wl.kernel_ms(a.steps))
     k_avg_ms = float(np.mean(k_ms))
     k_med_ms = float(k_ms[len(k_ms) // 2])
 
-    extras = {}
-    if a.extras and rank == 0:
-        def time_it(fn, steps):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize(dev)
-            t = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize(dev)
-            return (time.perf_counter() - t) / steps
-        ch.set_filter_mode(0xB1)
-        x256 = x[:256].contiguous()
-        o256 = out[:256]
-        dt = time_it(lambda: ch.process_f32(x256, out=o256), 50)
-        extras["config2_bypass_b256"] = {"frames_per_s": 256 / dt, "GBps": 256 * BYTES_PER_FRAME_F32 / dt / 1e9}
-        dt = time_it(step, a.steps)
-        extras["bypass_b4096"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
-        xqs = [torch.randint(-2048, 2048, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
-               for _ in range(R)]
-        oqs = [torch.empty((B, N, 2), dtype=torch.int16, device=dev) for _ in range(R)]
-        ch.reserve(B)
-        qstep_no = [0]
-
-        def qstep():
-            i = qstep_no[0] % R
-            qstep_no[0] += 1
-            ch.process_q15(xqs[i], out=oqs[i])
-        for name, cmd in (("config4_q15_default_iir", 0x00), ("q15_bypass", 0xB1)):
-            ch.set_filter_mode(cmd)
-            dt = time_it(qstep, 5)
-            extras[name] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+    extras = wl.extras(a.steps) if (a.extras and rank == 0 and not stub) else {}
 
     if rank == 0:
-        # HBM traffic per launch from the committed PMC passes of this same kernel and batch (counters
-        # cannot be read inside the timed process); null when the profile is for another batch size
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                pj = json.load(fh)
-            if pj.get("batch") == B:
-                traffic = pj["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        # HBM traffic per launch: FETCH_SIZE (doubled, gfx950) + WRITE_SIZE from the committed separate
+        # --pmc passes over this same kernel and batch (profiles/, tools/pmc_profile.sh).  Counters cannot be
+        # read inside the timed process, so this is a constant quoted from that profile -- `traffic_source`
+        # says which -- and null when the profile was taken at another batch size.
+        traffic, traffic_src = None, None
+        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pj = json.load(fh)
+                if pj.get("batch") == B:
+                    traffic, traffic_src = pj["traffic_bytes_per_launch"], f"profiles/{name}"
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         achieved = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
         line = {
             "metric": "16K-pt frames/sec (window+IIR+FFT), batch=4096",
@@ -227,24 +366,28 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "stub (no device work: control-plane rehearsal)" if stub else "synthetic",
             "config": {"workload": f"batch={B}x16K fp32 frames per GPU, Hann + 6-biquad IIR (12th-order Butterworth "
-                                   f"wn=0.2) + 16K FFT + magnitude, all 16384 bins written (BASELINE.json configs[2])",
+                                   f"wn=0.2) + 16K FFT + magnitude, all 16384 bins written (BASELINE.json configs[2]"
+                                   f"{'; x' + str(world) + ' GPUs = configs[4]' if world > 1 else ''})",
                        "frames_per_gpu": B, "sharding": "batch, independent per-GPU streams, no collective",
-                       "buffer_pairs": R},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "chain_f32_kernel<IIR,MAG_FULL>", "kernel_ms_avg": round(k_avg_ms, 4),
-                         "kernel_ms_median": round(k_med_ms, 4),
-                         "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32},
+                       "buffer_pairs": R, "seeds": [10 + r for r in range(world)]},
         }
+        if not stub:
+            line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                "traffic_source": traffic_src,
+                                "kernel": wl.kernel_name, "kernel_ms_avg": round(k_avg_ms, 4),
+                                "kernel_ms_median": round(k_med_ms, 4),
+                                "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32}
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if extras:
             line["extras"] = extras
         print(json.dumps(line), flush=True)
-    ch.close()
+    wl.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -64,3 +64,57 @@ def test_shard_helper_edges():
     assert shard_frames(10, 0, 3) == (0, 4) and shard_frames(10, 1, 3) == (4, 7) and shard_frames(10, 2, 3) == (7, 10)
     assert shard_frames(0, 0, 2) == (0, 0)
     assert shard_frames(4096, 0, 1) == (0, 4096)
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ, SA_BENCH_STUB="1", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (BASELINE.json configs[4] launched from the
+    bench itself): the launcher starts two fresh rank processes, rank 0 reports n_gpus == 2 and the
+    aggregate is 2 x 4096 frames per step over the MAX of the ranks' times.  The device step is stubbed
+    (SA_BENCH_STUB=1: no GPU here); rank set-up, gloo barrier, MAX-reduce and the JSON line are the real code."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {})
+    assert rc == 0, err
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["seeds"] == [10, 11] and line["config"]["frames_per_gpu"] == 4096
+    # the stub's rank 1 sleeps twice as long as rank 0: the timed region must be rank 1's (MAX over ranks)
+    assert line["ms_per_step"] >= 4.0
+    assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
+    assert "roofline" not in line and line["data"].startswith("stub")
+
+
+def test_bench_under_torchrun_env_and_mismatch():
+    """The torchrun contract keeps working (one rank per process, env-driven), and a --gpus / WORLD_SIZE
+    mismatch is an error instead of a silent n_gpus = 1."""
+    rc, lines, err = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "0"], {})
+    assert rc == 0 and lines[0]["n_gpus"] == 1, err
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and not lines and "WORLD_SIZE" in err
+    port = _free_port()
+    import subprocess
+    envs = [dict(os.environ, SA_BENCH_STUB="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(2)]
+    ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                           env=e, stdout=subprocess.PIPE, text=True) for e in envs]
+    outs = [p.communicate(timeout=300)[0] for p in ps]
+    assert all(p.returncode == 0 for p in ps)
+    assert '"n_gpus": 2' in outs[0] and "{" not in outs[1]              # only rank 0 prints the JSON line
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies takes the launch down with a non-zero exit code instead of leaving the others in the barrier."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"SA_BENCH_STUB_FAIL_RANK": "1"})
+    assert rc != 0 and not lines
