@@ -83,24 +83,72 @@ __global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__
     }
 }
 
+// plain copy, one 16-byte element per thread (grid = n16 / 256): the simplest "float4 copy"
+template <bool NT>
+__global__ __launch_bounds__(256) void copy1_kernel(const f4v *__restrict__ in, f4v *__restrict__ out, size_t n16)
+{
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n16) {
+        if (NT) __builtin_nontemporal_store(in[i], out + i);
+        else out[i] = in[i];
+    }
+}
+
+// grid-stride copy with U independent 16-byte loads in flight per thread
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copyu_kernel(const f4v *__restrict__ in, f4v *__restrict__ out, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += stride * U) {
+        f4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (i + u * stride < n16) ? in[i + u * stride] : f4v{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < n16) {
+                if (NT) __builtin_nontemporal_store(v[u], out + i + u * stride);
+                else out[i + u * stride] = v[u];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void read_kernel(const f4v *__restrict__ in, float *__restrict__ sink, size_t n16)
+{
+    f4v acc = {0, 0, 0, 0};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) acc += in[i];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = 1.f;
+}
+
+__global__ __launch_bounds__(256) void write_kernel(f4v *__restrict__ out, size_t n16)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(f4v{1.f, 2.f, 3.f, 4.f}, out + i);
+}
+
+// Timing: TRAIN launches back to back between one pair of events (no host sync inside the train), buffers
+// rotated launch by launch; the figure is the train's duration / TRAIN.  A single launch per event pair pays
+// the ramp and the tail of every launch and reads 3-6 % low.
+// usage: frame_stream [batch] [rot] [train]
 int main(int argc, char **argv)
 {
     const int batch = argc > 1 ? atoi(argv[1]) : 4096;
     const size_t bytes = (size_t)batch * N * 4;
     // ROT input and output buffers used round-robin: with one pair the 256 MiB input of a 4096-frame batch
     // stays in the 256 MB Infinity Cache from one launch to the next (streaming stores do not displace it)
-    // and the "HBM" figure becomes a cache figure.  frame_stream [batch] [rot]
-    const int ROT = argc > 2 ? atoi(argv[2]) : 1;
+    // and the "HBM" figure becomes a cache figure.
+    const int ROT = argc > 2 ? atoi(argv[2]) : 6;
+    const int TRAIN = argc > 3 ? atoi(argv[3]) : 60;
     std::vector<float *> ins(ROT), outs(ROT);
     for (int r = 0; r < ROT; ++r) {
         hipMalloc(&ins[r], bytes);
         hipMalloc(&outs[r], bytes);
-        hipMemset(ins[r], 0, bytes);
+        hipMemset(ins[r], 0x3c, bytes);          // non-zero, non-denormal floats
     }
-    float *in = ins[0], *out = outs[0];
     float4 *table;
     hipMalloc(&table, 16 * 256 * 16);
     hipMemset(table, 0, 16 * 256 * 16);
+    float *sink;
+    hipMalloc(&sink, 64);
     auto k1 = frame_kernel<1, false, 0>;
     auto k2 = frame_kernel<2, false, 0>;
     auto k3 = frame_kernel<3, false, 0>;
@@ -113,31 +161,78 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const char *names[8] = {"grid-stride copy", "frame/WG, linear stores", "frame/WG, split-step store streams",
-                            "frame/WG, split stores + 64 KiB table reads", "grid-stride copy, nontemporal stores",
-                            "frame/WG, split stores, nontemporal", "frame/WG, split nt stores + 64 KiB table reads",
-                            "frame/WG, split nt stores, nt DMA loads"};
-    for (int pass = 0; pass < 2; ++pass)
-        for (int var = 0; var < 8; ++var) {
-            std::vector<float> ms;
-            for (int rep = 0; rep < 60; ++rep) {
-                in = ins[rep % ROT];
-                out = outs[rep % ROT];
-                hipEventRecord(e0);
-                if (var == 0) hipLaunchKernelGGL(copy_kernel<false>, dim3(256 * 16), dim3(256), 0, 0, (const f4v *)in, (f4v *)out, bytes / 16);
-                else if (var == 4) hipLaunchKernelGGL(copy_kernel<true>, dim3(256 * 16), dim3(256), 0, 0, (const f4v *)in, (f4v *)out, bytes / 16);
-                else hipLaunchKernelGGL(ks[var], dim3(batch), dim3(256), kLds, 0, in, out, table, batch);
-                hipEventRecord(e1);
-                hipEventSynchronize(e1);
-                float m;
-                hipEventElapsedTime(&m, e0, e1);
-                if (rep >= 20) ms.push_back(m);
-            }
-            std::sort(ms.begin(), ms.end());
-            const double med = ms[ms.size() / 2];
-            if (pass == 1)
-                printf("rot=%d %-48s median %7.1f us  min %7.1f us  -> %6.2f TB/s (read+write)\n", ROT, names[var], med * 1e3, ms[0] * 1e3,
-                       2.0 * bytes / (med * 1e-3) / 1e12);
+    const size_t n16 = bytes / 16;
+    struct Var { const char *name; int kind; int arg; double bytes_moved; };
+    std::vector<Var> vars;
+    const int grids[] = {256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 32, 256 * 64};
+    static char nm[64][96];
+    int nn = 0;
+    for (int g : grids) { snprintf(nm[nn], 96, "grid-stride copy, grid %5d", g); vars.push_back({nm[nn++], 0, g, 2.0 * bytes}); }
+    for (int g : grids) { snprintf(nm[nn], 96, "grid-stride copy nt stores, grid %5d", g); vars.push_back({nm[nn++], 1, g, 2.0 * bytes}); }
+    vars.push_back({"copy, one 16 B element per thread", 2, 0, 2.0 * bytes});
+    vars.push_back({"copy, one element per thread, nt stores", 3, 0, 2.0 * bytes});
+    for (int g : {256 * 4, 256 * 8, 256 * 16}) { snprintf(nm[nn], 96, "copy 4 loads in flight, nt, grid %5d", g); vars.push_back({nm[nn++], 4, g, 2.0 * bytes}); }
+    for (int g : {256 * 4, 256 * 8}) { snprintf(nm[nn], 96, "copy 8 loads in flight, nt, grid %5d", g); vars.push_back({nm[nn++], 5, g, 2.0 * bytes}); }
+    vars.push_back({"read only (grid 4096)", 6, 256 * 16, 1.0 * bytes});
+    vars.push_back({"write only nt (grid 4096)", 7, 256 * 16, 1.0 * bytes});
+    const char *fnames[8] = {"", "frame/WG, linear stores", "frame/WG, split-step store streams",
+                             "frame/WG, split stores + 64 KiB table reads", "",
+                             "frame/WG, split stores, nontemporal", "frame/WG, split nt stores + 64 KiB table reads",
+                             "frame/WG, split nt stores, nt DMA loads"};
+    for (int v = 1; v < 8; ++v)
+        if (ks[v]) vars.push_back({fnames[v], 10 + v, 0, 2.0 * bytes});
+
+    auto launch = [&](const Var &v, int rep) {
+        const float *in = ins[rep % ROT];
+        float *out = outs[rep % ROT];
+        const dim3 blk(256);
+        switch (v.kind) {
+            case 0: hipLaunchKernelGGL(copy_kernel<false>, dim3(v.arg), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 1: hipLaunchKernelGGL(copy_kernel<true>, dim3(v.arg), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 2: hipLaunchKernelGGL(copy1_kernel<false>, dim3((unsigned)(n16 / 256)), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 3: hipLaunchKernelGGL(copy1_kernel<true>, dim3((unsigned)(n16 / 256)), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 4: hipLaunchKernelGGL((copyu_kernel<4, true>), dim3(v.arg), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 5: hipLaunchKernelGGL((copyu_kernel<8, true>), dim3(v.arg), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
+            case 6: hipLaunchKernelGGL(read_kernel, dim3(v.arg), blk, 0, 0, (const f4v *)in, sink, n16); break;
+            case 7: hipLaunchKernelGGL(write_kernel, dim3(v.arg), blk, 0, 0, (f4v *)out, n16); break;
+            default: hipLaunchKernelGGL(ks[v.kind - 10], dim3(batch), blk, kLds, 0, in, out, table, batch); break;
         }
+    };
+    // settle the clock: 0.4 s of sustained copies
+    for (int i = 0; i < 4000; ++i) launch(vars[3], i);
+    hipDeviceSynchronize();
+    printf("batch %d (%.0f MiB in + %.0f MiB out per launch), %d rotating buffer pairs, %d launches per timed train\n", batch,
+           bytes / 1048576.0, bytes / 1048576.0, ROT, TRAIN);
+    for (const Var &v : vars) {
+        std::vector<float> per;
+        for (int round = 0; round < 7; ++round) {
+            for (int i = 0; i < 5; ++i) launch(v, i);
+            hipEventRecord(e0);
+            for (int i = 0; i < TRAIN; ++i) launch(v, i);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float m;
+            hipEventElapsedTime(&m, e0, e1);
+            per.push_back(m / TRAIN);
+        }
+        // one launch per event pair, as round 1 measured it
+        std::vector<float> single;
+        for (int i = 0; i < 30; ++i) {
+            hipEventRecord(e0);
+            launch(v, i);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float m;
+            hipEventElapsedTime(&m, e0, e1);
+            single.push_back(m);
+        }
+        std::sort(per.begin(), per.end());
+        std::sort(single.begin(), single.end());
+        const double med = per[per.size() / 2];
+        printf("%-46s train median %7.1f us min %7.1f us -> %5.2f TB/s | single-launch median %7.1f us -> %5.2f TB/s\n", v.name,
+               med * 1e3, per[0] * 1e3, v.bytes_moved / (med * 1e-3) / 1e12, single[single.size() / 2] * 1e3,
+               v.bytes_moved / (single[single.size() / 2] * 1e-3) / 1e12);
+        fflush(stdout);
+    }
     return 0;
 }
