@@ -297,6 +297,17 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// a * w with w wave-uniform (an SGPR pair): two packed ops, no copy of w into VGPRs
+__device__ __forceinline__ cf cmul_s(const cf a, const float2 wu)
+{
+    const cf w = {wu.x, wu.y};
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));                 // a.x * (w.x, w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                        // + a.y * (-w.y, w.x)
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+
 // Split step of the packed real FFT for the bin pair (k, 8192-k):
 //   Xe = Z[k] + conj Z[M-k],  Xo = -i (Z[k] - conj Z[M-k]),  X[k] = Xe + W_N^k Xo,  X[M-k] = conj(Xe - W_N^k Xo)
 // (the 1/2 of the textbook form is already in the window table).  With s = Z[k] + Z[M-k], d = Z[k] - Z[M-k]:
@@ -376,9 +387,9 @@ template <int NSEC, bool UNIT, int OUT>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
-                                                                 const float4 *__restrict__ twA,
+                                                                 const float4 *__restrict__ twT,
                                                                  const float4 *__restrict__ twB,
-                                                                 const float2 *__restrict__ twP,
+                                                                 const float2 *__restrict__ twC,
                                                                  const SaIirLaneTab *__restrict__ lanetab,
                                                                  const SaIirK ka)
 {
@@ -398,6 +409,9 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     const float *xin = in + (size_t)f * SA_NPTS;
     constexpr bool IIR = NSEC > 0;
     cf a[32];
+#ifdef SA_STAMPS
+    if (threadIdx.x == 0) g_sa_stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
     SA_STAMP(0);
 
     if constexpr (IIR) {
@@ -463,13 +477,28 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 
     // ---- pass A: 32-point FFT over m1 (stride 256), then twiddle W_8192^(k1*m2), m2 = t
     SA_STAMP(3);
-    safft::fft_dit<32>(a);
+    // the thread's twiddle anchors (requested before the butterflies, consumed after them): W^(b t) for
+    // b = 1..7 and W^(8 a t) for a = 1..3 with W = W_8192, plus W_16384^(4 t) for the split step.  The 31
+    // factors W^(k1 t), k1 = 8a + b, are applied as two complex products per point; the 64 KiB table of all
+    // of them (one 16-byte load per two points, every frame, through L2 -> L1) is what this replaces:
+    // 24 KiB of anchors per frame, and the loads no longer sit between the butterflies and the exchange.
+    float4 an[6];
 #pragma unroll
-    for (int pp = 0; pp < 16; ++pp) {                      // twA4[pp][t] = (W^(2pp * t), W^((2pp+1) * t))
-        const float4 w = twA[pp * 256 + t];
-        if (pp > 0) a[2 * pp] = safft::cmul(a[2 * pp], {w.x, w.y});
-        a[2 * pp + 1] = safft::cmul(a[2 * pp + 1], {w.z, w.w});
+    for (int i = 0; i < 6; ++i) an[i] = twT[i * 256 + t];
+    safft::fft_dit<32>(a);
+    {
+        const cf wb[8] = {{1.f, 0.f}, {an[0].x, an[0].y}, {an[0].z, an[0].w}, {an[1].x, an[1].y},
+                          {an[1].z, an[1].w}, {an[2].x, an[2].y}, {an[2].z, an[2].w}, {an[3].x, an[3].y}};
+        const cf wa[4] = {{1.f, 0.f}, {an[3].z, an[3].w}, {an[4].x, an[4].y}, {an[4].z, an[4].w}};
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            if ((k1 & 7) != 0) a[k1] = safft::cmul(a[k1], wb[k1 & 7]);
+            if ((k1 >> 3) != 0) a[k1] = safft::cmul(a[k1], wa[k1 >> 3]);
+        }
     }
+    // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255
+    // (its neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0)
+    const cf wP = {an[5].x, an[5].y}, wPn = {an[5].z, an[5].w};
     SA_STAMP(4);
     // ---- exchange A -> B in two rounds of 16 rows; FFT q of a thread lives in round q:
     //      k1 = 16q + 4 wave + kq, b = lo; inputs ldc[row][16 a + b] with row pitch 272
@@ -548,10 +577,19 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
         for (int jj = 0; jj < 2; ++jj) {
             const int q0 = 4 * (t + 256 * jj);                 // k0 - 2048 r: bins q0 .. q0+4 of this round
             const int k0 = q0 + 2048 * r;
-            const float4 w01 = *reinterpret_cast<const float4 *>(twP + k0);
-            const float4 w23 = *reinterpret_cast<const float4 *>(twP + k0 + 2);
-            const float2 w4 = twP[k0 + 4];
-            const cf w[5] = {{w01.x, w01.y}, {w01.z, w01.w}, {w23.x, w23.y}, {w23.z, w23.w}, {w4.x, w4.y}};
+            // W_16384^(k0 + e) = W^(4 t) * W^(2048 r + 1024 jj + e): the second factor is the same for every
+            // thread (twC, scalar loads), the first is the thread's anchor -- no per-bin table
+            cf w[5];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = cmul_s(wP, twC[(2 * r + jj) * 5 + e]);
+            // bin k0 + 4 is bin 0 of the neighbouring group, which also stores it: the mirrored halves of the
+            // spectrum stay bit-identical only if both evaluate the same product, so this is the NEIGHBOUR's
+            // twiddle for its e = 0, anchor(t + 1) * C[block][0], with the block advancing at t = 255
+            {
+                const float2 c0 = twC[(2 * r + jj) * 5], c1 = twC[(2 * r + jj + 1) * 5];
+                const cf csel = (t == 255) ? cf{c1.x, c1.y} : cf{c0.x, c0.y};
+                w[4] = safft::cmul(wPn, csel);
+            }
             // a group of four bins never straddles a padding or row boundary, so four positions serve
             // the ten reads: low members q0+e at pa+e (e<4) and pb; partners at pm0, pm4+3, pm4+2, pm4+1, pm4
             const int pa = zpos_low(q0), pb = zpos_low(q0 + 4);
@@ -575,6 +613,14 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     __builtin_amdgcn_s_waitcnt(0);      // drain the stores so the last stamp sees them retire
 #endif
     SA_STAMP(12);
+#ifdef SA_STAMPS
+    if (threadIdx.x == 0) {             // placement and wall-clock end (100 MHz counter, the same on every XCD)
+        g_sa_stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+        g_sa_stamps[(size_t)blockIdx.x * 16 + 15] =
+            (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
@@ -662,8 +708,8 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
         auto kern = chain_f32_kernel<NSEC, UNIT, OUTK>;                                                \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twA, \
-                           tb.twB, tb.twP, tb.lanetab, ka);                                            \
+        hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, \
+                           tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
     switch (out_kind) {
         case SA_OUT_MAG_FULL: SA_LAUNCH(SA_OUT_MAG_FULL); break;

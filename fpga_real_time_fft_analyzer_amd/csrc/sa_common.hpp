@@ -73,9 +73,12 @@ struct SaF32Tables {
     const float4 *win_b;       // [16][256] 0.5 * window in the pass-A layout of the no-IIR kernel:
                                //   win_b[p][t] = w[512(2p)+2t], w[..+1], w[512(2p+1)+2t], w[..+1]
     const float4 *win_t;       // [16][256] the same, transposed: win_t[g][t] = win_half[64t + 4g .. +3]
-    const float4 *twA;         // [16][256]  (W_8192^(2p*m2), W_8192^((2p+1)*m2))
+    const float4 *twT;         // [6][256]   per-thread twiddle anchors, row i holds two complex values for thread t:
+                               //   rows 0..3: W^(1t) W^(2t) | W^(3t) W^(4t) | W^(5t) W^(6t) | W^(7t) W^(8t)   (W = W_8192)
+                               //   row 4:     W^(16t) W^(24t)          row 5: W_16384^(4t), W_16384^(4((t+1) & 255))
     const float4 *twB;         // [8][16]    (W_256^(2p*b),   W_256^((2p+1)*b))
-    const float2 *twP;         // [4097]     W_16384^k
+    const float2 *twC;         // [25]       W_16384^(1024 blk + e), index blk * 5 + e, blk = 2r + jj (+1): the wave-uniform
+                               //            factor of the split-step twiddles
     const SaIirLaneTab *lanetab;   // device
     const SaIirK *iir;             // HOST pointer, copied into the kernel arguments (null = no IIR)
 };

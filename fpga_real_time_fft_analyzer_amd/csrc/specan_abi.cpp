@@ -187,8 +187,8 @@ struct sa_handle {
     // device tables
     float4 *d_win_b = nullptr;
     float4 *d_win_t = nullptr;
-    float4 *d_twA = nullptr, *d_twB = nullptr;
-    float2 *d_twP = nullptr;
+    float4 *d_twT = nullptr, *d_twB = nullptr;
+    float2 *d_twC = nullptr;
     SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
     int16_t *d_rom = nullptr;
     uint32_t *d_twq = nullptr;
@@ -357,9 +357,9 @@ int sa_create(int device, sa_handle **out)
     SA_HIPC(hipSetDevice(device));
     SA_HIPC(hipMalloc(&h->d_win_b, sizeof(float) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_win_t, sizeof(float) * SA_NPTS));
-    SA_HIPC(hipMalloc(&h->d_twA, sizeof(float4) * 16 * 256));
+    SA_HIPC(hipMalloc(&h->d_twT, sizeof(float4) * 6 * 256));
     SA_HIPC(hipMalloc(&h->d_twB, sizeof(float4) * 8 * 16));
-    SA_HIPC(hipMalloc(&h->d_twP, sizeof(float2) * 4100));
+    SA_HIPC(hipMalloc(&h->d_twC, sizeof(float2) * 25));
     SA_HIPC(hipMalloc(&h->d_lt_default, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
@@ -377,27 +377,36 @@ int sa_create(int device, sa_handle **out)
         h->half_win = half;
         SA_HIPC(hipMemcpy(h->d_win_b, pa.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_win_t, tr.data(), sizeof(float) * SA_NPTS, hipMemcpyHostToDevice));
-        std::vector<float4> ta(16 * 256), tb(8 * 16);
-        std::vector<float2> tp(4100);
-        for (int pp = 0; pp < 16; ++pp)                    // pairs of twiddle rows: one 16-byte load feeds two points
-            for (int m2 = 0; m2 < 256; ++m2) {
-                const double a0 = -2.0 * M_PI * (double)(2 * pp * m2) / 8192.0;
-                const double a1 = -2.0 * M_PI * (double)((2 * pp + 1) * m2) / 8192.0;
-                ta[pp * 256 + m2] = make_float4((float)std::cos(a0), (float)std::sin(a0), (float)std::cos(a1), (float)std::sin(a1));
+        std::vector<float4> ta(6 * 256), tb(8 * 16);
+        std::vector<float2> tc(25);
+        auto w8192 = [](long e) {                          // exp(-2 pi i e / 8192), e reduced first (exact)
+            const double a = -2.0 * M_PI * (double)(e % 8192) / 8192.0;
+            return make_float2((float)std::cos(a), (float)std::sin(a));
+        };
+        for (int t = 0; t < 256; ++t) {                    // per-thread anchors (SaF32Tables::twT)
+            const int k[10] = {1, 2, 3, 4, 5, 6, 7, 8, 16, 24};
+            for (int i = 0; i < 5; ++i) {
+                const float2 u = w8192((long)k[2 * i] * t), v = w8192((long)k[2 * i + 1] * t);
+                ta[i * 256 + t] = make_float4(u.x, u.y, v.x, v.y);
             }
+            const double ap = -2.0 * M_PI * (double)(4 * t) / 16384.0;
+            const double an = -2.0 * M_PI * (double)(4 * ((t + 1) & 255)) / 16384.0;      // (1, 0) for t = 255
+            ta[5 * 256 + t] = make_float4((float)std::cos(ap), (float)std::sin(ap), (float)std::cos(an), (float)std::sin(an));
+        }
         for (int pp = 0; pp < 8; ++pp)
             for (int b = 0; b < 16; ++b) {
                 const double a0 = -2.0 * M_PI * (double)(2 * pp * b) / 256.0;
                 const double a1 = -2.0 * M_PI * (double)((2 * pp + 1) * b) / 256.0;
                 tb[pp * 16 + b] = make_float4((float)std::cos(a0), (float)std::sin(a0), (float)std::cos(a1), (float)std::sin(a1));
             }
-        for (int k = 0; k < 4100; ++k) {
-            const double ang = -2.0 * M_PI * (double)k / 16384.0;
-            tp[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-        }
-        SA_HIPC(hipMemcpy(h->d_twA, ta.data(), sizeof(float4) * ta.size(), hipMemcpyHostToDevice));
+        for (int blk = 0; blk < 5; ++blk)                   // block 4 = bin 4096 only (the seam of the last group)
+            for (int e = 0; e < 5; ++e) {
+                const double ang = -2.0 * M_PI * (double)(1024 * blk + e) / 16384.0;
+                tc[blk * 5 + e] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        SA_HIPC(hipMemcpy(h->d_twT, ta.data(), sizeof(float4) * ta.size(), hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float4) * tb.size(), hipMemcpyHostToDevice));
-        SA_HIPC(hipMemcpy(h->d_twP, tp.data(), sizeof(float2) * tp.size(), hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twC, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
     // IIR plans: default = the fixed ALPHA/BETA cascade as real taps; custom = cleared coefficients
     {
@@ -437,9 +446,9 @@ int sa_destroy(sa_handle *h)
     (void)hipDeviceSynchronize();
     (void)hipFree(h->d_win_b);
     (void)hipFree(h->d_win_t);
-    (void)hipFree(h->d_twA);
+    (void)hipFree(h->d_twT);
     (void)hipFree(h->d_twB);
-    (void)hipFree(h->d_twP);
+    (void)hipFree(h->d_twC);
     (void)hipFree(h->d_lt_default);
     (void)hipFree(h->d_lt_custom);
     (void)hipFree(h->d_rom);
@@ -664,7 +673,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     SA_HIP(h, hipSetDevice(h->device));
     // The section coefficients travel by value in the kernel arguments (stream-ordered by
     // construction); only the small per-lane table lives in device memory.
-    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twA, h->d_twB, h->d_twP, h->d_lt_custom, nullptr};
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;

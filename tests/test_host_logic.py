@@ -1,8 +1,10 @@
 """CPU: host-side logic -- designer/quantiser mirror, frame helpers, IIR plan algebra."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import N, load_golden, rel_maxnorm
+from conftest import N, ROOT, load_golden, rel_maxnorm
 from fpga_real_time_fft_analyzer_amd import designer, frames
 
 
@@ -289,3 +291,20 @@ def test_udp_emit_loopback():
         got = asm.add(rx.recv(2048), 0)
     rx.close()
     assert got == frame
+
+
+def test_fft_regs_host(tmp_path):
+    """The in-register FFT building blocks (csrc/fft_regs.hpp: radix-2 DIT of 4..32 points with compile-time
+    twiddles, the packed complex product) compiled for the HOST from the same header the kernels include and
+    checked against a naive float64 DFT (tests/cpp/test_fft_regs.cpp; <= 5e-7 max-norm relative)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "tests", "cpp", "test_fft_regs.cpp")
+    exe = str(tmp_path / "test_fft_regs")
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-host-only", "-x", "hip", src, "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fft32" in r.stdout

@@ -83,6 +83,29 @@ __global__ __launch_bounds__(256, 4) void frame_kernel(const float *__restrict__
     }
 }
 
+// variant D: no LDS-DMA, no transposition -- thread t loads ITS OWN 256 contiguous bytes (64 samples, the IIR's
+// chunk layout) with 16 x 16-byte loads; lanes of one load instruction are 256 B apart, each 128-byte line
+// is completed by 8 instructions of the same wave.  Stores: linear 16 B per lane (through registers only:
+// the data is permuted, this measures the memory system, not a usable kernel).
+template <bool NT, int HALVES>
+__global__ __launch_bounds__(256, 4) void direct_kernel(const float *__restrict__ in, float *__restrict__ out, int batch)
+{
+    const int t = threadIdx.x;
+    const int f = blockIdx.x;
+    if (f >= batch) return;
+    const float4 *src = reinterpret_cast<const float4 *>(in + (size_t)f * N + 64 * t);
+    float *o = out + (size_t)f * N;
+    float4 v[16];
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+        for (int g = 0; g < 16 / HALVES; ++g) v[h * (16 / HALVES) + g] = src[h * (16 / HALVES) + g];
+        if (HALVES > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st16<NT>(o + (g * 256 + t) * 4, v[g]);
+}
+
 // plain copy, one 16-byte element per thread (grid = n16 / 256): the simplest "float4 copy"
 template <bool NT>
 __global__ __launch_bounds__(256) void copy1_kernel(const f4v *__restrict__ in, f4v *__restrict__ out, size_t n16)
@@ -181,6 +204,8 @@ int main(int argc, char **argv)
                              "frame/WG, split nt stores, nt DMA loads"};
     for (int v = 1; v < 8; ++v)
         if (ks[v]) vars.push_back({fnames[v], 10 + v, 0, 2.0 * bytes});
+    vars.push_back({"frame/WG, per-thread 256 B direct loads, nt st", 20, 0, 2.0 * bytes});
+    vars.push_back({"frame/WG, direct loads in 2 waited halves, nt", 21, 0, 2.0 * bytes});
 
     auto launch = [&](const Var &v, int rep) {
         const float *in = ins[rep % ROT];
@@ -195,6 +220,8 @@ int main(int argc, char **argv)
             case 5: hipLaunchKernelGGL((copyu_kernel<8, true>), dim3(v.arg), blk, 0, 0, (const f4v *)in, (f4v *)out, n16); break;
             case 6: hipLaunchKernelGGL(read_kernel, dim3(v.arg), blk, 0, 0, (const f4v *)in, sink, n16); break;
             case 7: hipLaunchKernelGGL(write_kernel, dim3(v.arg), blk, 0, 0, (f4v *)out, n16); break;
+            case 20: hipLaunchKernelGGL((direct_kernel<true, 1>), dim3(batch), blk, 0, 0, in, out, batch); break;
+            case 21: hipLaunchKernelGGL((direct_kernel<true, 2>), dim3(batch), blk, 0, 0, in, out, batch); break;
             default: hipLaunchKernelGGL(ks[v.kind - 10], dim3(batch), blk, kLds, 0, in, out, table, batch); break;
         }
     };
