@@ -117,13 +117,22 @@ __device__ __forceinline__ void store_nt(float *p, float a) { __builtin_nontempo
 // and multiplies by the window, which the host stored transposed (wint[g][t] = window[64t + 4g .. +3])
 // so that its loads are coalesced in this layout.
 // Thread t ends with d[j] = (x[64t + j], x[64t + 32 + j]) * window.
+template <bool WINGEN>
 __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, const float4 *__restrict__ wint,
-                                                unsigned char *smem, int t, v2f (&d)[32])
+                                                const SaIirLaneTab *__restrict__ lt, unsigned char *smem, int t,
+                                                v2f (&d)[32])
 {
     const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
     const int lane = t & 63, wave = t >> 6;
     // per-lane byte offset of its 16-byte source column inside the slab of 8 chunk rows (256 B apart)
     const int rl = lane >> 3;                                  // row inside the slab
+    // WINGEN: the window a0 - a1 cos(theta n) evaluated in place (see stage_in_direct): W = G0 + P_h c_j + Q_h s_j
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float g0 = 0.f;
+    if constexpr (WINGEN) {
+        pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);
+        g0 = lt->wg0;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1) __syncthreads();          // round-0 readers are done with the image
@@ -140,12 +149,22 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();                      // waits for the DMA (vmcnt) and publishes the image
         const int sw = (t >> 1) & 7;
+        const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             // two batches of four units: all eight in flight at once push the kernel over 128 VGPRs
             if (g == 4) __builtin_amdgcn_sched_barrier(0);
-            const float4 w = wint[(8 * h + g) * 256 + t];
             const float4 q = lds4[t * 8 + (g ^ sw)];
+            float4 w;
+            if constexpr (WINGEN) {
+                float wv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    wv[e] = __builtin_fmaf(Q, lt->wcs[4 * g + e][1], __builtin_fmaf(P, lt->wcs[4 * g + e][0], g0));
+                w = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            } else {
+                w = wint[(8 * h + g) * 256 + t];
+            }
             // mul_to: one v_mul_f32 straight into its half of the (chunk A, chunk B) pair.  Left to the
             // SLP vectoriser the two rounds become v_pk_mul_f32 on re-paired operands: ~100 v_mov per thread.
             if (h == 0) {
@@ -164,31 +183,107 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// One cascade section, in place on the thread's two chunks.
-//   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
-//   z1,z2 (out): the same for the NEXT section (accumulated while this section's outputs appear)
-template <bool PREDICT_NEXT, bool UNIT>
-__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const float2 *__restrict__ mt_next,
-                                            const float4 lanep, float2 *scr_s, int lane, int wave, v2f &z1, v2f &z2)
+// Stage-in for the IIR without LDS: thread t loads ITS OWN 64 consecutive samples (256 bytes) with sixteen
+// 16-byte loads.  The lanes of one load instruction are 256 bytes apart, but each 128-byte line is completed by
+// eight instructions of the same wave, and the memory system delivers this pattern at the rate of a coalesced
+// stream (profiles/r2_memory_skeleton.txt: 5.66 TB/s against 5.5-5.8 TB/s for the LDS-DMA form).  No DMA, no
+// transposition through LDS, no barrier, and all sixteen loads are in flight at once.
+//
+// Window.  WINGEN: the window is a0 - a1 cos(2 pi n / (N-1)) (Hann, Hamming; what scripts/hann_coeff.py:3-4
+// generates) and is evaluated in place by the angle-addition formula: with n = 64 t + 32 h + j,
+//   W[n] = G0 + P_h c_j + Q_h s_j,   c_j = cos(theta j), s_j = sin(theta j) wave-uniform (scalar loads),
+//   (P_h, Q_h) = S a1 (-cos, sin)(theta (64 t + 32 h)) per thread and chunk, G0 = S a0, S = 0.5 * cascade gain;
+// two packed FMAs give (W of chunk A, W of chunk B) for one j.  The 64 KiB per-frame read of the window table
+// (L2 -> L1, 16 more loads per thread) is gone.  !WINGEN (any other window): the transposed table as before.
+// Thread t ends with d[j] = (x[64t + j], x[64t + 32 + j]) * window.
+template <bool WINGEN>
+__device__ __forceinline__ void stage_in_direct(const float *__restrict__ xin, const SaIirLaneTab *__restrict__ lt,
+                                                int t, v2f (&d)[32])
 {
-    // the next section's predictor taps: 64 wave-uniform floats, requested before the scan so that the
-    // four scalar loads are in flight across its barrier instead of being waited for one by one inside
-    // the recursion (the empty asm below pins them: "in SGPRs by here")
-    float m1n[32], m2n[32];
-    if constexpr (PREDICT_NEXT) {
+    const float4 *src = reinterpret_cast<const float4 *>(xin + 64 * t);
+    float4 qa[8], qb[8];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float2 mm = mt_next[j];
-            m1n[j] = mm.x;
-            m2n[j] = mm.y;
+    for (int g = 0; g < 8; ++g) {
+        qa[g] = src[g];
+        qb[g] = src[8 + g];
+    }
+    if constexpr (WINGEN) {
+        const float4 pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);      // P_A, Q_A, P_B, Q_B
+        const v2f P = {pq.x, pq.z}, Q = {pq.y, pq.w};
+        const float g0s = lt->wg0;
+        const v2f G0 = {g0s, g0s};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float xa[4] = {qa[g].x, qa[g].y, qa[g].z, qa[g].w}, xb[4] = {qb[g].x, qb[g].y, qb[g].z, qb[g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * g + e;
+                const v2f cs = {lt->wcs[j][0], lt->wcs[j][1]};                       // wave-uniform: SGPR pair
+                v2f w;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(w) : "v"(P), "s"(cs), "v"(G0));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(w) : "v"(Q), "s"(cs));
+                d[j].x = mul_to(xa[e], w.x);
+                d[j].y = mul_to(xb[e], w.y);
+            }
+        }
+    } else {
+        const float4 *wint = reinterpret_cast<const float4 *>(lt->win_t);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 wa = wint[g * 256 + t], wb = wint[(8 + g) * 256 + t];
+            d[4 * g + 0] = v2f{mul_to(qa[g].x, wa.x), mul_to(qb[g].x, wb.x)};
+            d[4 * g + 1] = v2f{mul_to(qa[g].y, wa.y), mul_to(qb[g].y, wb.y)};
+            d[4 * g + 2] = v2f{mul_to(qa[g].z, wa.z), mul_to(qb[g].z, wb.z)};
+            d[4 * g + 3] = v2f{mul_to(qa[g].w, wa.w), mul_to(qb[g].w, wb.w)};
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// n1 += m1 * y, n2 += m2 * y with (m1, m2) one wave-uniform tap pair in an aligned SGPR pair: the halves are picked
+// with op_sel.  Written as `m1 * y` the compiler first copies every odd-numbered SGPR into an even one (one
+// s_mov_b32 per tap, 192 per frame and wave).
+__device__ __forceinline__ void tap_fma(v2f &n1, v2f &n2, const v2f tap, const v2f y)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(n1) : "s"(tap), "v"(y));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(n2) : "s"(tap), "v"(y));
+}
+
+// The wave-uniform constants of one section, read one section ahead (while the previous section's loops run)
+// so that their scalar-load latency is not on the path between two sections.
+struct SecConsts {
+    float pc0, pc1, pc2, pc3, mb0, mb1, mb2, mb3, b0, b1, b2, a1, a2, flags_bits;     // flags travel as raw bits
+};
+__device__ __forceinline__ SecConsts load_consts(const SaIirSecK &k)
+{
+    return {k.pc[0], k.pc[1], k.pc[2], k.pc[3], k.mback[0], k.mback[1], k.mback[2], k.mback[3],
+            k.c[0], k.c[1], k.c[2], k.c[3], k.c[4], __builtin_bit_cast(float, k.flags)};
+}
+__device__ __forceinline__ void pin_consts(const SecConsts &c)
+{
+    asm volatile("" ::"s"(c.pc0), "s"(c.pc1), "s"(c.pc2), "s"(c.pc3), "s"(c.mb0), "s"(c.mb1), "s"(c.mb2), "s"(c.mb3),
+                 "s"(c.b1), "s"(c.a1), "s"(c.a2), "s"(c.flags_bits));
+}
+
+// One cascade section, in place on the thread's two chunks.
+//   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
+//   z1,z2 (out): the same for the NEXT section
+//   c  (in)    : this section's constants;   cn (out): the next section's, requested here
+// Two loops: the recursion (3 scalar constants), then the next section's predictor over the fresh outputs (its
+// 32 tap pairs, requested before the recursion so that they arrive under it).  Fused into one loop the 64 tap
+// registers are live from the top of the section and, with the section constants, exceed the 102 SGPRs a wave
+// has: the compiler then reloads them piecemeal, and every reload is an exposed scalar-load round trip.
+template <bool PREDICT_NEXT, bool UNIT>
+__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const SaIirSecK &knext, const SecConsts c,
+                                            SecConsts &cn, const float4 lanep, float2 *scr_s, int lane, int wave,
+                                            v2f &z1, v2f &z2)
+{
     // state after both chunks of this thread, from zero state: zT = Pc zA + zB
-    float t1 = __builtin_fmaf(k.pc[0], z1.x, __builtin_fmaf(k.pc[1], z2.x, z1.y));
-    float t2 = __builtin_fmaf(k.pc[2], z1.x, __builtin_fmaf(k.pc[3], z2.x, z2.y));
+    float t1 = __builtin_fmaf(c.pc0, z1.x, __builtin_fmaf(c.pc1, z2.x, z1.y));
+    float t2 = __builtin_fmaf(c.pc2, z1.x, __builtin_fmaf(c.pc3, z2.x, z2.y));
     // inclusive affine scan inside the 16-lane row; levels whose transition power has decayed below
     // float resolution are skipped (wave-uniform flags from the host)
-    const int flags = k.flags;
+    const int flags = __builtin_bit_cast(int, c.flags_bits);
     if (!(flags & 1)) scan_level<1>(t1, t2, k.plev[0]);
     if (!(flags & 2)) scan_level<2>(t1, t2, k.plev[1]);
     if (!(flags & 4)) scan_level<4>(t1, t2, k.plev[2]);
@@ -223,20 +318,18 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
     // start state of chunk A: row-local part + P2^i * (row start state); chunk B: Pc sA + zA
     const float a1s = __builtin_fmaf(lanep.x, c1, __builtin_fmaf(lanep.y, c2, e1));
     const float a2s = __builtin_fmaf(lanep.z, c1, __builtin_fmaf(lanep.w, c2, e2));
-    const float b1s = __builtin_fmaf(k.pc[0], a1s, __builtin_fmaf(k.pc[1], a2s, z1.x));
-    const float b2s = __builtin_fmaf(k.pc[2], a1s, __builtin_fmaf(k.pc[3], a2s, z2.x));
+    const float b1s = __builtin_fmaf(c.pc0, a1s, __builtin_fmaf(c.pc1, a2s, z1.x));
+    const float b2s = __builtin_fmaf(c.pc2, a1s, __builtin_fmaf(c.pc3, a2s, z2.x));
     // pole coordinates -> DF2T states of the recursion (sa_common.hpp)
     const v2f q1 = {a1s, b1s}, q2 = {a2s, b2s};
-    v2f s1 = k.mback[0] * q1 + k.mback[1] * q2, s2 = k.mback[2] * q1 + k.mback[3] * q2;
-    const float b0 = k.c[0], b1 = k.c[1], b2 = k.c[2], na1 = -k.c[3], na2 = -k.c[4];
-    v2f n1 = {0.f, 0.f}, n2 = {0.f, 0.f};
+    v2f s1 = c.mb0 * q1 + c.mb1 * q2, s2 = c.mb2 * q1 + c.mb3 * q2;
+    // the next section's tap pairs: requested now, consumed after the recursion
+    v2f tp[32];
     if constexpr (PREDICT_NEXT) {
 #pragma unroll
-        for (int j = 0; j < 32; j += 8)
-            asm volatile("" ::"s"(m1n[j]), "s"(m1n[j + 1]), "s"(m1n[j + 2]), "s"(m1n[j + 3]), "s"(m1n[j + 4]), "s"(m1n[j + 5]),
-                         "s"(m1n[j + 6]), "s"(m1n[j + 7]), "s"(m2n[j]), "s"(m2n[j + 1]), "s"(m2n[j + 2]), "s"(m2n[j + 3]),
-                         "s"(m2n[j + 4]), "s"(m2n[j + 5]), "s"(m2n[j + 6]), "s"(m2n[j + 7]));
+        for (int j = 0; j < 32; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
     }
+    const float b0 = c.b0, b1 = c.b1, b2 = c.b2, na1 = -c.a1, na2 = -c.a2;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const v2f x = d[j];
@@ -251,15 +344,20 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
             s2 = na2 * y + b2 * x;
         }
         d[j] = y;
-        if constexpr (PREDICT_NEXT) {
-            // wave-uniform taps: SGPR operands of the packed FMAs (as LDS broadcasts they cost 40 % of
-            // the kernel's LDS cycles)
-            n1 += m1n[j] * y;
-            n2 += m2n[j] * y;
-        }
     }
-    z1 = n1;
-    z2 = n2;
+    if constexpr (PREDICT_NEXT) {
+        cn = load_consts(knext);
+        // four accumulators: each chain sees a dependent FMA every fourth instruction
+        v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 32; j += 2) {
+            tap_fma(n1a, n2a, tp[j], d[j]);
+            tap_fma(n1b, n2b, tp[j + 1], d[j + 1]);
+        }
+        z1 = n1a + n1b;
+        z2 = n2a + n2b;
+        pin_consts(cn);
+    }
 }
 
 // All NSEC sections run unconditionally (the host pads shorter cascades with identity sections,
@@ -267,16 +365,14 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
 // through control-flow merges and cost ~190 register copies.
 template <int S, int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
-                                             float2 *scr, int lane, int wave, v2f &z1, v2f &z2)
+                                             float2 *scr, int lane, int wave, v2f &z1, v2f &z2, const SecConsts c)
 {
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
-        if constexpr (S + 1 < NSEC)
-            iir_section<true, UNIT>(d, ka.sec[S], reinterpret_cast<const float2 *>(&lt->m[S + 1][0][0]), lanep,
-                                    scr + 16 * S, lane, wave, z1, z2);
-        else
-            iir_section<false, UNIT>(d, ka.sec[S], nullptr, lanep, scr + 16 * S, lane, wave, z1, z2);
-        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, z1, z2);
+        SecConsts cn = c;
+        iir_section<(S + 1 < NSEC), UNIT>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + 16 * S, lane,
+                                          wave, z1, z2);
+        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, z1, z2, cn);
     }
 }
 
@@ -284,16 +380,17 @@ template <int NSEC, bool UNIT>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
                                             float2 *scr, int t)
 {
-    // predictor for the first section (later ones are fused into the recursion loops)
-    v2f z1 = {0.f, 0.f}, z2 = {0.f, 0.f};
-    const float2 *__restrict__ m0 = reinterpret_cast<const float2 *>(&lt->m[0][0][0]);
+    // predictor for the first section (later ones run after the previous section's recursion)
+    const SecConsts c0 = load_consts(ka.sec[0]);
+    v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const float2 mm = m0[j];
-        z1 += mm.x * d[j];
-        z2 += mm.y * d[j];
+    for (int j = 0; j < 32; j += 2) {
+        tap_fma(n1a, n2a, v2f{ka.m0[j][0], ka.m0[j][1]}, d[j]);
+        tap_fma(n1b, n2b, v2f{ka.m0[j + 1][0], ka.m0[j + 1][1]}, d[j + 1]);
     }
-    iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, z1, z2);
+    v2f z1 = n1a + n1b, z2 = n2a + n2b;
+    pin_consts(c0);
+    iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, z1, z2, c0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,7 +480,7 @@ __device__ __forceinline__ int zpos_low(int q) { return zrow_pos(q, q >> 9); }
 __device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w >> 9)) & 7); }
 
 // ---------------------------------------------------------------------------------------------
-template <int NSEC, bool UNIT, int OUT>
+template <int NSEC, bool UNIT, int OUT, bool WINGEN>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
@@ -416,7 +513,11 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 
     if constexpr (IIR) {
         v2f d[32];
-        stage_in_chunks(xin, reinterpret_cast<const float4 *>(lanetab->win_t), smem, t, d);
+#if defined(SA_STAGE_DIRECT)
+        stage_in_direct<WINGEN>(xin, lanetab, t, d);
+#else
+        stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
+#endif
         SA_STAMP(1);
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
         SA_STAMP(2);
@@ -638,7 +739,7 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     if (f >= batch) return;
     v2f d[32];
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
-    stage_in_chunks(in + (size_t)f * SA_NPTS, wint, smem, t, d);
+    stage_in_chunks<false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
     // Stage-out, the stage-in run backwards: each thread owns 64 consecutive samples, so storing straight
     // from the registers puts every lane of a store instruction into another 256-byte block (measured 5x
@@ -670,20 +771,10 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     }
 }
 
-// Raise the dynamic-LDS limit once per kernel and device (not a stream operation: doing it on every
-// launch costs host time and is not capturable into a hipGraph).
 template <typename K>
 hipError_t set_lds(K kernel)
 {
-    static bool done[64] = {false};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsBytes);
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
-    return e;
+    return sa_set_dyn_lds_once(reinterpret_cast<const void *>(kernel), kLdsBytes);
 }
 
 }  // namespace
@@ -705,7 +796,8 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
     hipError_t e = hipSuccess;
 #define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
-        auto kern = chain_f32_kernel<NSEC, UNIT, OUTK>;                                                \
+        auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0)>                          \
+                              : chain_f32_kernel<NSEC, UNIT, OUTK, false>;                             \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
         hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, \

@@ -461,26 +461,16 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     if (batch <= 0) return hipSuccess;
     const dim3 grid(batch), block(kFftThreads);
     const int lds = SA_NPTS * 4;
-    static bool attr_done[2][64] = {{false}};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const bool known = dev >= 0 && dev < 64;
+    hipError_t e;
     if (apply_window) {
         auto k = fft_q15_kernel<true>;
-        if (!known || !attr_done[1][dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            if (known) attr_done[1][dev] = true;
-        }
+        e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
     } else {
         auto k = fft_q15_kernel<false>;
-        if (!known || !attr_done[0][dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            if (known) attr_done[0][dev] = true;
-        }
+        e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
     }
     return hipGetLastError();

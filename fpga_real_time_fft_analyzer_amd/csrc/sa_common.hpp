@@ -14,7 +14,8 @@
 //   y = b0 x + s1;  s1' = b1 x - a1 y + s2;  s2' = b2 x - a2 y
 // with state transition A = [[-a1,1],[-a2,0]] and input vector Bv = [b1 - a1 b0, b2 - a2 b0].
 // Pc = A^32 (one chunk), P2 = A^64 (one thread = two chunks), Prow = A^1024 (one 16-lane row).
-// Everything here is wave-uniform and travels in the kernel argument segment (SGPRs).
+// Everything here, the predictor taps included, is wave-uniform and travels by value in the kernel-argument
+// segment (scalar loads; stream-ordered for free; 2.9 KiB of the 4 KiB a launch may carry).
 // flags: bit i (i = 0..3) set = in-row scan level 2^i is skipped because P2^(2^i) is below float
 // resolution (|entries| < 1e-10: its contribution is < 1e-10 of the state); bit 4 set = the same holds
 // for Prow, so the start state of a row is just the previous row's total (no scan over the rows).
@@ -27,6 +28,10 @@
 // mback = T^-1 (row-major) takes the two start states back to DF2T right before the recursion.  It is the
 // identity for first-order, repeated-pole and padding sections.
 struct SaIirSecK {
+    float mnext[SA_CHUNK][2];  // predictor taps (m1, m2) of the NEXT section (zero for the last one): its chunk end
+                               // states from zero state are accumulated while this section's outputs appear.
+                               // They sit in front of this section's own constants so that everything a section
+                               // needs is one contiguous run of scalar loads from the kernel-argument segment.
     float c[5];            // b0,b1,b2,a1,a2
     int flags;
     float pad[2];
@@ -41,19 +46,25 @@ struct SaIirK {
     int unit;              // 1: every section is in unit-numerator form b = [1, r1, 1] (cascade gain folded
                            //    into the window table of this plan); the recursion then needs 4 ops, not 5
     float gain;            // the folded cascade gain (1 when unit == 0); informational for tests
-    int pad;
+    int wingen;            // 1: the window is a0 - a1 cos(2 pi n / (N-1)) and the IIR kernels evaluate it in place
+                           //    (SaIirLaneTab::wgen / wcs / wg0); 0: they read the table win_t
+    float m0[SA_CHUNK][2]; // predictor taps of section 0: chunk end state from zero state = sum_j m0[j] x[j]
     SaIirSecK sec[SA_MAXSEC];
 };
 
 // device-memory part of the plan:
-//   m[s][j]   = predictor taps (m1, m2): chunk end state from zero state = sum_j m[s][j] x[j];
-//               read at wave-uniform addresses, i.e. through scalar loads into SGPR operands
 //   p[s][i]   = P2^i, i = lane index inside its 16-lane row (start-state injection per lane)
 //   win_t     = 0.5 * window * G, transposed for the chunk layout (win_t[g][t][e] = w[64t + 4g + e]);
 //               G = product of the sections' b0 when the plan is in unit-numerator form, else 1
+//   wgen, wcs, wg0 = the in-place window generator of the IIR kernels (chain_f32.hip, stage_in_direct):
+//               W[64t + 32h + j] = wg0 + wgen[t][2h] * wcs[j][0] + wgen[t][2h+1] * wcs[j][1], all including the
+//               factor 0.5 * G; valid when the plan's `wingen` flag is set
 struct SaIirLaneTab {
-    float m[SA_MAXSEC][SA_CHUNK][2];
     float p[SA_MAXSEC][16][4];
+    float wgen[SA_NTHREADS][4];
+    float wcs[SA_CHUNK][2];
+    float wg0;
+    float pad[3];
     float win_t[SA_NPTS];
 };
 
@@ -67,6 +78,10 @@ struct SaQ15Params {
     int8_t pad2[4];
     int16_t sos_q14[SA_MAXSEC * 6];
 };
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device); thread-safe (specan_abi.cpp).  Not a stream
+// operation: doing it on every launch costs host time and cannot be captured into a hipGraph.
+hipError_t sa_set_dyn_lds_once(const void *kernel, int bytes);
 
 // launchers (defined in chain_f32.hip / chain_q15.hip)
 struct SaF32Tables {

@@ -9,14 +9,20 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
 
-std::string g_create_error;
+// last sa_create() failure of the calling thread (sa_last_error(NULL)); per thread, so that concurrent creates on
+// several host threads -- one per GPU, SURVEY 8(e) -- do not race on it
+thread_local std::string g_create_error;
 
 // imp/filter_pkg.vhd:54-68, wire order B0,B1,B2,A0,A1,A2 per set (ALPHA then BETA)
 const int8_t kDefaultQ7[12] = {-14, 0, 14, 107, 21, 127, -15, 0, 15, 107, -21, 127};
@@ -54,7 +60,10 @@ inline void put(float *dst, const Mat2 &m)
 // sections are rewritten as b = [1, b1/b0, 1] and the product of the b0's is folded into this plan's
 // copy of the window: one multiply less per sample and section in the recursion.
 // half_win: 0.5 * window in natural order (size SA_NPTS).
-void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *lt, const float *half_win)
+// cosw: {a0, a1} when the window is a0 - a1 cos(2 pi n / (N-1)) (then the IIR kernels evaluate it in place,
+// see SaIirLaneTab::wgen), null for any other window.
+void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *lt, const float *half_win,
+                const double *cosw = nullptr)
 {
     std::memset(plan, 0, sizeof(*plan));
     std::memset(lt, 0, sizeof(*lt));
@@ -89,6 +98,22 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
             for (int g = 0; g < 16; ++g)
                 for (int e = 0; e < 4; ++e)
                     lt->win_t[(g * 256 + t) * 4 + e] = (float)((double)half_win[64 * t + 4 * g + e] * gain);
+    plan->wingen = 0;
+    if (half_win && cosw && !std::getenv("SA_NO_WINGEN")) {
+        const double theta = 2.0 * M_PI / (double)(SA_NPTS - 1), S = 0.5 * gain;
+        plan->wingen = 1;
+        lt->wg0 = (float)(S * cosw[0]);
+        for (int t = 0; t < SA_NTHREADS; ++t)
+            for (int h = 0; h < 2; ++h) {
+                const double a = theta * (double)(64 * t + 32 * h);
+                lt->wgen[t][2 * h] = (float)(-S * cosw[1] * std::cos(a));
+                lt->wgen[t][2 * h + 1] = (float)(S * cosw[1] * std::sin(a));
+            }
+        for (int j = 0; j < SA_CHUNK; ++j) {
+            lt->wcs[j][0] = (float)std::cos(theta * j);
+            lt->wcs[j][1] = (float)std::sin(theta * j);
+        }
+    }
     for (int s = 0; s < nsec; ++s) {
         const double *r = sos + 6 * s;
         const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
@@ -121,9 +146,10 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         put(sp.mback, M);
         double v0 = T.a * (b1 - a1 * b0) + T.b * (b2 - a2 * b0);      // T Bv
         double v1 = T.c * (b1 - a1 * b0) + T.d * (b2 - a2 * b0);
+        float (*mdst)[2] = s == 0 ? plan->m0 : plan->sec[s - 1].mnext;       // taps of section s ride with section s-1
         for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[j] = A^(31-j) Bv
-            lt->m[s][j][0] = (float)v0;
-            lt->m[s][j][1] = (float)v1;
+            mdst[j][0] = (float)v0;
+            mdst[j][1] = (float)v1;
             const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
             v0 = n0; v1 = n1;
         }
@@ -166,6 +192,20 @@ void sos_from_q7(const int8_t *c12, double *sos /*[6][6]*/)
 
 }  // namespace
 
+hipError_t sa_set_dyn_lds_once(const void *kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;        // (kernel, device)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
+}
+
 struct sa_handle {
     int device = 0;
     std::string err;
@@ -182,6 +222,8 @@ struct sa_handle {
     SaIirK plan_default{}, plan_custom{};
     SaIirLaneTab lt_default{}, lt_custom{};
     std::vector<float> half_win;           // 0.5 * float window, natural order
+    bool win_is_cos = true;                // the float window is a0 - a1 cos(2 pi n / (N-1)) (default: Hann)
+    double win_cos[2] = {0.5, 0.5};
     double sos_custom[36] = {0};          // a0-normalised custom cascade (kept to rebuild on window change)
     int nsec_custom = 0;
     // device tables
@@ -194,6 +236,23 @@ struct sa_handle {
     uint32_t *d_twq = nullptr;
     int16_t *d_work = nullptr;
     int work_frames = 0;
+    // ---- stream-ordered control plane (no device-wide synchronisation anywhere after sa_create)
+    // Table uploads run on the handle's own control stream: it first waits for everything the handle has
+    // launched so far (an event recorded on the data stream at upload time), copies from a pinned staging slot,
+    // and records `uploaded`; the next process call makes its stream wait for that event.  Other handles and
+    // other streams of the device are never stalled.
+    hipStream_t ctl = nullptr;
+    hipEvent_t launched = nullptr, uploaded = nullptr;
+    bool upload_pending = false;           // an upload was issued that the data stream has not waited for yet
+    hipStream_t data_stream = nullptr;     // stream of the most recent process call
+    bool have_data_stream = false;
+    static constexpr int kStage = 4;       // pinned staging slots (a slot is reused after kStage uploads)
+    void *stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stage_done[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_used[kStage] = {false, false, false, false};
+    int stage_next = 0;
+    // transport / sequencing state of imp/sequ2.vhd as far as the command bytes define it
+    uint8_t transport = SA_CMD_ETHERNET_MODE;     // ether_en <= '1' on reset (imp/sequ2.vhd:85-86)
 };
 
 namespace {
@@ -215,13 +274,48 @@ int fail(sa_handle *h, int code, const char *what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail((h), SA_EHIP, #call, e_); \
     } while (0)
 
+constexpr size_t kStageBytes = sizeof(SaIirLaneTab) > sizeof(float) * SA_NPTS ? sizeof(SaIirLaneTab) : sizeof(float) * SA_NPTS;
+
+// Stream-ordered table update (see sa_handle): after everything launched so far, before everything launched
+// later; asynchronous for the host except when all staging slots are still waiting for their copies.
 int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
 {
-    // Table updates are rare control-plane events: a full device sync makes them trivially ordered
-    // against every process call issued before and after.
+    if (bytes > kStageBytes) return fail(h, SA_EINVAL, "upload: table larger than the staging slot");
     SA_HIP(h, hipSetDevice(h->device));
-    SA_HIP(h, hipDeviceSynchronize());
-    SA_HIP(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) % sa_handle::kStage;
+    if (h->stage_used[slot]) SA_HIP(h, hipEventSynchronize(h->stage_done[slot]));   // that slot's old copy has run
+    std::memcpy(h->stage[slot], src, bytes);
+    if (h->have_data_stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->data_stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(h, SA_ESTATE, "control-plane call while the handle's stream is being captured into a graph");
+        SA_HIP(h, hipEventRecord(h->launched, h->data_stream));
+        SA_HIP(h, hipStreamWaitEvent(h->ctl, h->launched, 0));
+    }
+    SA_HIP(h, hipMemcpyAsync(dst, h->stage[slot], bytes, hipMemcpyHostToDevice, h->ctl));
+    SA_HIP(h, hipEventRecord(h->stage_done[slot], h->ctl));
+    h->stage_used[slot] = true;
+    SA_HIP(h, hipEventRecord(h->uploaded, h->ctl));
+    h->upload_pending = true;
+    return SA_OK;
+}
+
+// Called by every process entry point before it launches on `stream`: orders the launch after pending table
+// uploads and after the handle's earlier launches if the caller switched streams.
+int enter_stream(sa_handle *h, hipStream_t stream)
+{
+    if (h->have_data_stream && h->data_stream != stream) {
+        SA_HIP(h, hipEventRecord(h->launched, h->data_stream));
+        SA_HIP(h, hipStreamWaitEvent(stream, h->launched, 0));
+        h->upload_pending = true;            // the new stream has not seen the last upload either
+    }
+    if (h->upload_pending) {
+        SA_HIP(h, hipStreamWaitEvent(stream, h->uploaded, 0));
+        h->upload_pending = false;
+    }
+    h->data_stream = stream;
+    h->have_data_stream = true;
     return SA_OK;
 }
 
@@ -283,26 +377,61 @@ int upload_window_half(sa_handle *h, const std::vector<float> &half)
     return rebuild_plans(h);          // each plan carries its own (gain-scaled) copy of the window
 }
 
+// Is w[n] = a0 - a1 cos(2 pi n / (N-1)) to within float rounding?  Least-squares fit of (a0, a1) in double, then
+// the residual against 1.5e-7 of the window's peak: Hann, Hamming and every other two-term cosine window pass,
+// anything else (Blackman, Kaiser, rectangular with a taper, ...) keeps the table.
+bool fit_cosine_window(const float *w, double out[2])
+{
+    const double theta = 2.0 * M_PI / (double)(SA_NPTS - 1);
+    double s1 = 0, sc = 0, scc = 0, sw = 0, swc = 0, peak = 0;
+    for (int n = 0; n < SA_NPTS; ++n) {
+        const double c = -std::cos(theta * n), v = (double)w[n];
+        s1 += 1.0; sc += c; scc += c * c; sw += v; swc += v * c;
+        peak = std::fmax(peak, std::fabs(v));
+    }
+    const double det = s1 * scc - sc * sc;
+    if (!(det > 0.0) || !(peak > 0.0) || !std::isfinite(peak)) return false;
+    const double a0 = (sw * scc - swc * sc) / det, a1 = (s1 * swc - sc * sw) / det;
+    double worst = 0;
+    for (int n = 0; n < SA_NPTS; ++n) worst = std::fmax(worst, std::fabs((double)w[n] - (a0 - a1 * std::cos(theta * n))));
+    if (!(worst <= 1.5e-7 * peak)) return false;
+    out[0] = a0;
+    out[1] = a1;
+    return true;
+}
+
 int set_window_f32_from(sa_handle *h, const float *w)
 {
     std::vector<float> half(SA_NPTS);
     for (int i = 0; i < SA_NPTS; ++i) half[i] = 0.5f * w[i];
+    h->win_is_cos = fit_cosine_window(w, h->win_cos);
     return upload_window_half(h, half);
 }
 
-// flat float view for tests: SaIirK followed by SaIirLaneTab
+// flat float view for tests (layout documented in include/specan.h, sa_iir_plan_from_sos): header, the six
+// sections' constants, then the predictor taps m[6][32][2] and the per-lane matrices p[6][16][4]
 int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
 {
-    // the flat view stops before the per-plan window copy (tests read the taps and matrices only)
-    const int n1 = (int)(sizeof(SaIirK) / sizeof(float));
-    const int n2 = (int)((sizeof(lt.m) + sizeof(lt.p)) / sizeof(float));
-    if (out && cap > 0) {
-        std::vector<float> tmp(n1 + n2);
-        std::memcpy(tmp.data(), &p, sizeof(SaIirK));
-        std::memcpy(tmp.data() + n1, &lt, sizeof(float) * (size_t)n2);
-        std::memcpy(out, tmp.data(), sizeof(float) * (size_t)(cap < n1 + n2 ? cap : n1 + n2));
+    std::vector<float> v;
+    auto put_i = [&](int x) { float f; std::memcpy(&f, &x, 4); v.push_back(f); };
+    put_i(p.nsec); put_i(p.unit); v.push_back(p.gain); put_i(p.wingen);
+    for (int s = 0; s < SA_MAXSEC; ++s) {
+        const SaIirSecK &k = p.sec[s];
+        for (int i = 0; i < 5; ++i) v.push_back(k.c[i]);
+        put_i(k.flags); v.push_back(k.pad[0]); v.push_back(k.pad[1]);
+        v.insert(v.end(), k.pc, k.pc + 4);
+        v.insert(v.end(), k.mback, k.mback + 4);
+        v.insert(v.end(), &k.plev[0][0], &k.plev[0][0] + 16);
+        v.insert(v.end(), &k.prow[0][0], &k.prow[0][0] + 16);
     }
-    return n1 + n2;
+    for (int s = 0; s < SA_MAXSEC; ++s) {
+        const float (*m)[2] = s == 0 ? p.m0 : p.sec[s - 1].mnext;
+        v.insert(v.end(), &m[0][0], &m[0][0] + 2 * SA_CHUNK);
+    }
+    v.insert(v.end(), &lt.p[0][0][0], &lt.p[0][0][0] + SA_MAXSEC * 16 * 4);
+    const int n = (int)v.size();
+    if (out && cap > 0) std::memcpy(out, v.data(), sizeof(float) * (size_t)(cap < n ? cap : n));
+    return n;
 }
 
 int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
@@ -310,7 +439,7 @@ int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
     std::memset(h->sos_custom, 0, sizeof h->sos_custom);
     std::memcpy(h->sos_custom, sos_norm, sizeof(double) * 6 * (size_t)nsec);
     h->nsec_custom = nsec;
-    build_plan(h->sos_custom, nsec, &h->plan_custom, &h->lt_custom, h->half_win.data());
+    build_plan(h->sos_custom, nsec, &h->plan_custom, &h->lt_custom, h->half_win.data(), h->win_is_cos ? h->win_cos : nullptr);
     return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
@@ -318,10 +447,11 @@ int rebuild_plans(sa_handle *h)
 {
     double sos[36];
     sos_from_q7(kDefaultQ7, sos);
-    build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data());
+    const double *cw = h->win_is_cos ? h->win_cos : nullptr;
+    build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data(), cw);
     int rc = upload(h, h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab));
     if (rc != SA_OK) return rc;
-    build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data());
+    build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
     return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
@@ -355,6 +485,13 @@ int sa_create(int device, sa_handle **out)
         }                                                                  \
     } while (0)
     SA_HIPC(hipSetDevice(device));
+    SA_HIPC(hipStreamCreateWithFlags(&h->ctl, hipStreamNonBlocking));
+    SA_HIPC(hipEventCreateWithFlags(&h->launched, hipEventDisableTiming));
+    SA_HIPC(hipEventCreateWithFlags(&h->uploaded, hipEventDisableTiming));
+    for (int i = 0; i < sa_handle::kStage; ++i) {
+        SA_HIPC(hipHostMalloc(&h->stage[i], kStageBytes, hipHostMallocDefault));
+        SA_HIPC(hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming));
+    }
     SA_HIPC(hipMalloc(&h->d_win_b, sizeof(float) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_win_t, sizeof(float) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twT, sizeof(float4) * 6 * 256));
@@ -412,12 +549,12 @@ int sa_create(int device, sa_handle **out)
     {
         double sos[36];
         sos_from_q7(kDefaultQ7, sos);
-        build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data());
+        build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
         sos_from_q7(h->c12_custom, sos);
         std::memcpy(h->sos_custom, sos, sizeof sos);
         h->nsec_custom = 6;
-        build_plan(sos, 6, &h->plan_custom, &h->lt_custom, h->half_win.data());
+        build_plan(sos, 6, &h->plan_custom, &h->lt_custom, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
     }
     // integer tables
@@ -434,6 +571,7 @@ int sa_create(int device, sa_handle **out)
         }
         SA_HIPC(hipMemcpy(h->d_twq, tq.data(), sizeof(uint32_t) * SA_NPTS, hipMemcpyHostToDevice));
     }
+    SA_HIPC(hipDeviceSynchronize());          // creation only: the blocking copies above are complete
 #undef SA_HIPC
     *out = h;
     return SA_OK;
@@ -443,7 +581,15 @@ int sa_destroy(sa_handle *h)
 {
     if (!h) return SA_OK;
     (void)hipSetDevice(h->device);
-    (void)hipDeviceSynchronize();
+    if (h->have_data_stream) (void)hipStreamSynchronize(h->data_stream);     // this handle's work only
+    if (h->ctl) (void)hipStreamSynchronize(h->ctl);
+    for (int i = 0; i < sa_handle::kStage; ++i) {
+        if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+        if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
+    }
+    if (h->launched) (void)hipEventDestroy(h->launched);
+    if (h->uploaded) (void)hipEventDestroy(h->uploaded);
+    if (h->ctl) (void)hipStreamDestroy(h->ctl);
     (void)hipFree(h->d_win_b);
     (void)hipFree(h->d_win_t);
     (void)hipFree(h->d_twT);
@@ -464,7 +610,7 @@ int sa_reserve(sa_handle *h, int max_batch)
     if (max_batch < 0) return fail(h, SA_ESHAPE, "sa_reserve: negative batch");
     if (max_batch <= h->work_frames) return SA_OK;
     SA_HIP(h, hipSetDevice(h->device));
-    SA_HIP(h, hipDeviceSynchronize());
+    if (h->have_data_stream) SA_HIP(h, hipStreamSynchronize(h->data_stream));    // launches that use the old workspace
     if (h->d_work) SA_HIP(h, hipFree(h->d_work));
     h->d_work = nullptr;
     h->work_frames = 0;
@@ -600,6 +746,8 @@ int sa_set_window_f32(sa_handle *h, const float *w)
     default_window_f64(d);
     std::vector<float> half(SA_NPTS);
     for (int i = 0; i < SA_NPTS; ++i) half[i] = (float)(0.5 * d[i]);
+    h->win_is_cos = true;
+    h->win_cos[0] = h->win_cos[1] = 0.5;                  // scripts/hann_coeff.py:3-4
     return upload_window_half(h, half);
 }
 
@@ -631,6 +779,7 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
     if (batch == 0) return SA_OK;
     if (!in || !out_time) return fail(h, SA_EINVAL, "sa_filter_q15: NULL tensor");
     SA_HIP(h, hipSetDevice(h->device));
+    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
@@ -645,6 +794,7 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     if (batch == 0) return SA_OK;
     if (!in || !out_iq) return fail(h, SA_EINVAL, "sa_process_q15: NULL tensor");
     SA_HIP(h, hipSetDevice(h->device));
+    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
@@ -671,8 +821,9 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     if (h->filter_mode == SA_FILTER_WIDE)
         return fail(h, SA_ESTATE, "sa_process_f32: filter mode 0xA2 (Q2.14) belongs to the Q15 path; use 0xA1 with sa_load_sos_f32");
     SA_HIP(h, hipSetDevice(h->device));
-    // The section coefficients travel by value in the kernel arguments (stream-ordered by
-    // construction); only the small per-lane table lives in device memory.
+    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
+    // The section coefficients and predictor taps travel by value in the kernel arguments (stream-ordered
+    // by construction); the per-lane matrices and the window live in device memory (stream-ordered uploads).
     SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;

@@ -26,6 +26,12 @@ xs = [x] + [x.clone() for _ in range(ROT - 1)]
 outs = [out] + [torch.empty_like(x) for _ in range(ROT - 1)]
 libs = []
 for name in sys.argv[1:]:
+    # "lib.so:VAR=value" sets an environment variable while that library's handle is created (plan-time switches)
+    envset = None
+    if ":" in name:
+        name, envset = name.split(":", 1)
+        k, v = envset.split("=", 1)
+        os.environ[k] = v
     L = C.CDLL(os.path.join(PKG, name))
     h = C.c_void_p()
     assert L.sa_create(0, C.byref(h)) == 0
@@ -33,6 +39,9 @@ for name in sys.argv[1:]:
     L.sa_process_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.sa_set_filter_mode.argtypes = [C.c_void_p, C.c_uint8]
     assert L.sa_load_sos_f64(h, sos.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
+    if envset:
+        del os.environ[envset.split("=", 1)[0]]
+        name = name + ":" + envset
     libs.append((name, L, h))
 st = torch.cuda.current_stream().cuda_stream
 ROUNDS, REPS = 12, 40
