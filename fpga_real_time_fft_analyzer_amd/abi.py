@@ -23,6 +23,12 @@ SA_WIN_RTL_SIGNED, SA_WIN_HANN_U16 = 0, 1
 SA_OUT_MAG_FULL, SA_OUT_MAG_HALF, SA_OUT_SPEC_HALF, SA_OUT_TIME = 0, 1, 2, 3
 
 
+class CmdEvents(C.Structure):
+    """sa_cmd_events of include/specan.h."""
+    _fields_ = [("n_start", C.c_int), ("n_uart_request", C.c_int), ("n_reset", C.c_int), ("n_uploads", C.c_int),
+                ("control_changed", C.c_int), ("transport", C.c_uint8)]
+
+
 class SpecanError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"specan error {code}: {msg}")
@@ -71,6 +77,8 @@ def lib() -> C.CDLL:
     L.sa_load_coeffs_q7.argtypes = [H, C.POINTER(C.c_int8)]
     L.sa_get_coeffs_q7.argtypes = [H, C.POINTER(C.c_int8)]
     L.sa_feed_command_bytes.argtypes = [H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int)]
+    L.sa_feed_command_bytes_ex.argtypes = [H, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(CmdEvents)]
+    L.sa_get_transport.argtypes = [H, C.POINTER(C.c_uint8)]
     L.sa_load_sos_f32.argtypes = [H, C.POINTER(C.c_float), C.c_int]
     L.sa_load_sos_f64.argtypes = [H, C.POINTER(C.c_double), C.c_int]
     L.sa_load_sos_q14.argtypes = [H, C.POINTER(C.c_int16), C.c_int]
@@ -86,6 +94,7 @@ def lib() -> C.CDLL:
     L.sa_iir_plan_from_sos.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.c_int]
     for name in ("sa_create", "sa_destroy", "sa_abi_version", "sa_reserve", "sa_set_filter_mode",
                  "sa_get_filter_mode", "sa_load_coeffs_q7", "sa_get_coeffs_q7", "sa_feed_command_bytes",
+                 "sa_feed_command_bytes_ex", "sa_get_transport",
                  "sa_load_sos_f32", "sa_load_sos_f64", "sa_load_sos_q14", "sa_set_window_q15",
                  "sa_set_window_f32", "sa_set_window_mode_q15", "sa_get_window_q15", "sa_process_q15",
                  "sa_filter_q15", "sa_process_f32", "sa_pack_frame", "sa_debug_iir_plan_f32",

@@ -124,12 +124,26 @@ class SpectrumChain:
         return a
 
     def feed_command_bytes(self, data: bytes) -> int:
-        """Push raw UART bytes through the RX state machine; returns the number of frame requests
-        (0x55 / 0xA5) seen."""
+        """Push raw UART bytes through the RX state machine; returns the number of UART read requests
+        (0xA5, imp/sequ2.vhd:216) seen outside coefficient uploads."""
         buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_uint8 * 1)()
         n = C.c_int(0)
         self._check(self._lib.sa_feed_command_bytes(self._h, buf, len(data), C.byref(n)))
         return n.value
+
+    def feed_command_bytes_ex(self, data: bytes) -> "abi.CmdEvents":
+        """The same, reporting everything a transport shim needs (sa_cmd_events of include/specan.h)."""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_uint8 * 1)()
+        ev = abi.CmdEvents()
+        self._check(self._lib.sa_feed_command_bytes_ex(self._h, buf, len(data), C.byref(ev)))
+        return ev
+
+    @property
+    def transport(self) -> int:
+        """0xEF (Ethernet, the reset state: imp/sequ2.vhd:85-86) or 0xFE (UART)."""
+        v = C.c_uint8()
+        self._check(self._lib.sa_get_transport(self._h, C.byref(v)))
+        return v.value
 
     def send_filter_coefficients(self, quantized_sections) -> bytes:
         """Same wire bytes as UartReceiver.send_filter_coefficients (gui.py:591-613): 0xF1 then the

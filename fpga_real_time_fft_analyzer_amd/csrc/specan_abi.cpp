@@ -652,40 +652,63 @@ int sa_get_coeffs_q7(const sa_handle *h, int8_t c[12])
     return SA_OK;
 }
 
-int sa_feed_command_bytes(sa_handle *h, const uint8_t *bytes, size_t n, int *n_frames_requested)
+int sa_feed_command_bytes_ex(sa_handle *h, const uint8_t *bytes, size_t n, sa_cmd_events *ev)
 {
     if (!h) return SA_EINVAL;
     if (!bytes && n) return fail(h, SA_EINVAL, "sa_feed_command_bytes: NULL bytes");
     for (size_t i = 0; i < n; ++i) {
         const uint8_t b = bytes[i];
-        if (h->rx_count >= 0) {                      // ACQUIRE: busy, byte is a coefficient
-            h->rx_buf[h->rx_count++] = (int8_t)b;
-            if (h->rx_count == 12) {
+        if (h->rx_count >= 0) {                      // ACQUIRE: busy, byte is a coefficient; neither command_control
+            h->rx_buf[h->rx_count++] = (int8_t)b;    // nor sequ_2 sees it (uart_rx_valid and not busy,
+            if (h->rx_count == 12) {                 // imp/dsp_system_top.vhd:644, new/command_control.vhd:51)
                 h->rx_count = -1;
                 const int rc = sa_load_coeffs_q7(h, h->rx_buf);
                 if (rc != SA_OK) return rc;
+                if (ev) { ++ev->n_uploads; ev->control_changed = 1; }
             }
             continue;
         }
-        switch (b) {                                 // IDLE: command decode (command_control.vhd:53-62)
+        switch (b) {                                 // IDLE: command decode (command_control.vhd:53-62, sequ2.vhd:82-96)
             case SA_CMD_FILTER_UPDATE: h->rx_count = 0; break;
             case SA_FILTER_DEFAULT:
             case SA_FILTER_CUSTOM:
-            case SA_FILTER_NONE: h->filter_mode = b; break;
-            case SA_CMD_RESET: {                     // rst: mode B1 (:50), coefficients cleared (filter_iir12_cust.vhd:51-52)
-                h->filter_mode = SA_FILTER_NONE;
+            case SA_FILTER_NONE:
+                if (ev && h->filter_mode != b) ev->control_changed = 1;
+                h->filter_mode = b;
+                break;
+            case SA_CMD_RESET: {                     // rst: mode B1 (:50), coefficients cleared (filter_iir12_cust.vhd:51-52),
+                h->filter_mode = SA_FILTER_NONE;     // Ethernet transport (sequ2.vhd:85-86)
+                h->transport = SA_CMD_ETHERNET_MODE;
                 const int8_t z[12] = {0};
                 const int rc = sa_load_coeffs_q7(h, z);
                 if (rc != SA_OK) return rc;
+                if (ev) { ++ev->n_reset; ev->control_changed = 1; }
                 break;
             }
-            case SA_CMD_START:
-            case SA_CMD_UART_REQUEST:
-                if (n_frames_requested) ++*n_frames_requested;
-                break;
-            default: break;                          // 0xEF / 0xFE transport select and unknown bytes: no effect here
+            case SA_CMD_ETHERNET_MODE:
+            case SA_CMD_UART_MODE: h->transport = b; break;
+            case SA_CMD_START: if (ev) ++ev->n_start; break;
+            case SA_CMD_UART_REQUEST: if (ev) ++ev->n_uart_request; break;
+            default: break;                          // unknown bytes: no effect, like the RTL
         }
     }
+    if (ev) ev->transport = h->transport;
+    return SA_OK;
+}
+
+int sa_feed_command_bytes(sa_handle *h, const uint8_t *bytes, size_t n, int *n_frames_requested)
+{
+    sa_cmd_events ev;
+    std::memset(&ev, 0, sizeof ev);
+    const int rc = sa_feed_command_bytes_ex(h, bytes, n, &ev);
+    if (n_frames_requested) *n_frames_requested += ev.n_uart_request;
+    return rc;
+}
+
+int sa_get_transport(const sa_handle *h, uint8_t *cmd)
+{
+    if (!h || !cmd) return SA_EINVAL;
+    *cmd = h->transport;
     return SA_OK;
 }
 

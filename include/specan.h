@@ -17,9 +17,14 @@
  *     sa_create() fails with SA_EHIP.
  *   - the library never allocates, frees or retains caller tensors.  It owns the opaque handle,
  *     its device-side tables and (for the Q15 IIR modes) a workspace sized by sa_reserve().
- *   - a handle is not thread-safe; use one handle per (GPU, stream).  process calls are
- *     asynchronous on the given stream; mode / coefficient / window changes are stream-ordered:
- *     they apply to every process call issued after them.
+ *   - a handle is not thread-safe; use one handle per (GPU, stream) -- different handles may be
+ *     used from different host threads at the same time (one thread per GPU).
+ *     Process calls are asynchronous on the given stream; mode / coefficient / window changes are
+ *     stream-ordered: they apply to every process call issued after them and to none issued
+ *     before.  No call after sa_create() synchronises the device: table uploads run on the
+ *     handle's own control stream behind an event, so other handles and streams are not stalled.
+ *     Control-plane calls are not allowed while the handle's stream is being captured into a
+ *     hipGraph (SA_ESTATE); process calls are capturable once sa_reserve() has sized the workspace.
  *   - frame length is fixed: SA_N = 16384 samples (gui.py:43-44, imp/dsp_system_top.vhd:440,
  *     ip/xfft_0/xfft_0.xci:12).
  */
@@ -35,7 +40,7 @@ extern "C" {
 
 #define SA_N 16384
 #define SA_FRAME_BYTES 65536          /* gui.py:42  FRAME_SIZE_BYTES */
-#define SA_ABI_VERSION 1
+#define SA_ABI_VERSION 2
 
 /* error codes */
 #define SA_OK       0
@@ -102,8 +107,24 @@ int sa_get_coeffs_q7(const sa_handle *h, int8_t c[12]);
  * byte is interpreted as a command; 0x00/0xA1/0xB1 select the filter; 0xFF resets (filter NONE,
  * coefficients cleared); 0x55/0xA5/0xEF/0xFE are accepted and counted but have no effect on the
  * signal path.  Unknown bytes are ignored, like the RTL.  *n_frames_requested (optional) is
- * incremented once per 0xA5 / 0x55 seen, so a transport shim knows to emit frames. */
+ * incremented once per 0xA5 seen outside a coefficient upload: the UART read request of
+ * imp/sequ2.vhd:216 (0x55 only starts the acquisition, new/command_control.vhd:58-60, and is
+ * reported by sa_feed_command_bytes_ex). */
 int sa_feed_command_bytes(sa_handle *h, const uint8_t *bytes, size_t n, int *n_frames_requested);
+
+/* The same front door with everything a transport shim needs to stand where imp/sequ2.vhd stands.
+ * Counters are ADDED to (zero the struct first); `transport` and `control_changed` are set. */
+typedef struct sa_cmd_events {
+    int n_start;          /* 0x55: start_aq pulse (new/command_control.vhd:58-60, :75) */
+    int n_uart_request;   /* 0xA5: UART read command (imp/sequ2.vhd:216) */
+    int n_reset;          /* 0xFF: reset_n pulse (new/command_control.vhd:56-57) */
+    int n_uploads;        /* completed 0xF1 + 12-byte coefficient uploads (new/rx_filter_coeff.vhd:45-56) */
+    int control_changed;  /* non-zero: filter select, coefficients or a reset changed what the path computes */
+    uint8_t transport;    /* SA_CMD_ETHERNET_MODE or SA_CMD_UART_MODE after the last byte (imp/sequ2.vhd:82-96);
+                             reset selects Ethernet (imp/sequ2.vhd:85-86) */
+} sa_cmd_events;
+int sa_feed_command_bytes_ex(sa_handle *h, const uint8_t *bytes, size_t n, sa_cmd_events *ev);
+int sa_get_transport(const sa_handle *h, uint8_t *cmd);
 
 /* North-star wide formats (not in the reference): up to 6 independent sections, scipy row order
  * [b0,b1,b2,a0,a1,a2], normalised by a0 on load.  f32/f64 feed sa_process_f32 in CUSTOM mode;

@@ -52,7 +52,7 @@ def test_build_then_smoke_in_one_process():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import __graft_entry__ as g; from fpga_real_time_fft_analyzer_amd import abi; "
-            "assert abi.lib().sa_abi_version() == 1; g.smoke()")
+            "assert abi.lib().sa_abi_version() == 2; g.smoke()")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "smoke ok" in r.stdout

@@ -242,9 +242,14 @@ def test_batch_beyond_two_gib(ch, torch_mod):
 
 
 def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
-    """N1/N2: the board as gui.py sees it -- command bytes in, frames / datagrams out."""
+    """N1/N2: the board as gui.py sees it -- command bytes in, frames / datagrams out, sequenced like
+    imp/sequ2.vhd: Ethernet after reset, 0x55 arms the UART and the first 0xA5 starts a CONTINUOUS byte stream
+    (what gui.py:529-549 sends and :616-689 slices), frames computed ahead are dropped when the control state
+    changes, coefficient bytes are never commands."""
+    import socket
+    import threading
     from fpga_real_time_fft_analyzer_amd import designer, frames
-    from fpga_real_time_fft_analyzer_amd.virtual_fpga import VirtualFpga
+    from fpga_real_time_fft_analyzer_amd.virtual_fpga import VirtualFpga, VirtualSerial
     rng = np.random.default_rng(8)
     src_frames = rng.integers(-2048, 2048, size=(6, N)).astype(np.int16)
     served = []
@@ -254,31 +259,73 @@ def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
         served.extend(range(i, i + n))
         return src_frames[[j % 6 for j in range(i, i + n)]]
 
+    def ref_frame(idx, cmd, c12=None):
+        return oracle.chain_q15(src_frames[idx % 6][None, :], None, 0, cmd, c12, None)[0].astype("<i2").tobytes()
+
     fpga = VirtualFpga(source, device=0, batch=3)
+    ser = VirtualSerial.factory(fpga)("COM5", 230400, timeout=0.001, writeTimeout=0.5, exclusive=True)   # gui.py:468-477
+    assert ser.is_open and fpga.transport == "ETHERNET" and not fpga.started                             # sequ2.vhd:85-86
+    ser.reset_input_buffer()
+    ser.reset_output_buffer()
     q = designer.two_sections_for_fpga(designer.quantize_coefficients(designer.design_iir_filter("lowpass", 4, 10.0, 20.0, 100.0)))
-    fpga.write(designer.coefficient_upload_bytes(q) + bytes([0xA1, 0x55]))     # upload, select custom, start
-    assert fpga.read() != b"" or True
-    fpga.read()
-    fpga.write(bytes([0xA5]))                                                 # UART frame request (gui.py:28)
-    f1 = fpga.read()
-    assert len(f1) == 65536
-    ref = oracle.chain_q15(src_frames[1:2], None, 0, 0xA1, np.array(q, np.int8).reshape(12), None)
-    assert f1 == ref[0].astype("<i2").tobytes()                               # second frame: 0x55 took the first
-    # coefficient bytes equal to 0xA5 must not trigger frames
-    fpga.write(bytes([0xF1] + [0xA5] * 12))
-    assert fpga.read() == b""
-    # Ethernet mode: 64 datagrams reassemble to the frame
-    fpga.write(bytes([0xEF, 0xB1, 0xA5]))
-    dg = fpga.read_datagrams()
-    assert len(dg) == 64 and all(len(d) == 1025 for d in dg)
+    c12 = np.array(q, np.int8).reshape(12)
+    # UART session exactly as the GUI runs it: mode byte, upload, select custom, 0x55, (100 ms), 0xA5
+    ser.write(bytes([0xFE]))
+    ser.write(designer.coefficient_upload_bytes(q) + bytes([0xA1]))
+    ser.write(bytes([0x55]))
+    ser.flush()
+    assert fpga.uart_state == "IDLE2" and ser.in_waiting == 0 and ser.read(4096) == b""                 # armed, silent
+    ser.write(bytes([0xA5]))
+    assert fpga.uart_state == "STREAM"
+    got = bytearray()
+    while len(got) < 2 * 65536:                                                                        # gui.py:616-627
+        n = min(ser.in_waiting, 4096)
+        assert n > 0
+        got += ser.read(n)
+    assert bytes(got[:65536]) == ref_frame(0, 0xA1, c12) and bytes(got[65536:2 * 65536]) == ref_frame(1, 0xA1, c12)
+    # a control change drops what was computed ahead (batch = 3: frame 2 is pending with the old filter):
+    # the next frame on the wire is a NEW acquisition filtered with the new setting
+    ser.reset_input_buffer()
+    ser.write(bytes([0xB1]))
+    nxt = ser.read(65536)
+    assert len(nxt) == 65536 and nxt == ref_frame(3, 0xB1)
+    # coefficient bytes equal to command values (0xA5, 0xEF, 0xFF, 0x55) are data, not commands
+    ser.reset_input_buffer()
+    ser.write(bytes([0xF1] + [0xA5, 0xEF, 0xFF, 0x55] * 3))
+    assert fpga.transport == "UART" and fpga.uart_state == "STREAM"
+    assert list(fpga.chain.coeffs_q7().view(np.uint8)) == [0xA5, 0xEF, 0xFF, 0x55] * 3
+    # Ethernet: switching idles both machines until a new 0x55; then 64 datagrams per frame reassemble
+    ser.write(bytes([0xEF]))
+    assert fpga.transport == "ETHERNET" and not fpga.started and fpga.read_datagrams() == [] and ser.in_waiting == 0
+    ser.write(bytes([0xB1, 0x55]))
+    dg = fpga.read_datagrams(2)
+    assert len(dg) == 128 and all(len(d) == 1025 for d in dg) and [d[0] for d in dg[:64]] == list(range(64))
     asm = frames.FrameAssembler()
-    got = None
-    for d in dg:
-        got = asm.add(d, 0)
-    assert got is not None and len(got) == 65536
-    assert len(list(fpga.stream(4))) == 4
-    fpga.write(bytes([0xFF]))                                                 # reset
-    assert fpga.chain.filter_mode == 0xB1 and not fpga.started
+    out = [fr for fr in (asm.add(d, 0) for d in dg) if fr is not None]
+    assert len(out) == 2 and all(len(fr) == 65536 for fr in out)
+    # UDP serve loop against a plain socket on the GUI's port layout (any free port here), capped frame rate
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(5.0)
+    th = threading.Thread(target=fpga.serve_udp, kwargs=dict(addr=rx.getsockname(), n_frames=3, fps_limit=200.0))
+    t0 = __import__("time").monotonic()
+    th.start()
+    asm, got_frames = frames.FrameAssembler(), []
+    while len(got_frames) < 3:
+        fr = asm.add(rx.recv(2048), 0)
+        if fr is not None:
+            got_frames.append(fr)
+    th.join(timeout=10)
+    rx.close()
+    assert __import__("time").monotonic() - t0 >= 2 / 200.0 and all(frames.decode_mag_16iq_le(fr).shape == (N,) for fr in got_frames)
+    # reset: Ethernet, idle, bypass, coefficients cleared
+    ser.write(bytes([0xFE, 0x55, 0xFF]))
+    assert fpga.transport == "ETHERNET" and not fpga.started and fpga.chain.filter_mode == 0xB1
+    assert not fpga.chain.coeffs_q7().any()
+    ser.close()
+    assert not ser.is_open
+    with pytest.raises(OSError):
+        ser.write(b"\x55")
     fpga.close()
 
 
