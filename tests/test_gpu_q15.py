@@ -153,14 +153,20 @@ def test_command_byte_stream(ch, torch_mod, oracle):
     ch.feed_command_bytes(bytes([0xF1] + [0x00, 0xB1, 0xFF, 0x55, 0xA5, 0xF1, 1, 2, 3, 4, 5, 6]))
     assert ch.filter_mode == 0xA1
     assert ch.coeffs_q7().tolist() == [0, -79, -1, 0x55, -91, -15, 1, 2, 3, 4, 5, 6]
-    # split delivery, unknown bytes ignored, frame requests counted
-    assert ch.feed_command_bytes(bytes([0x42, 0x55, 0xA5, 0xEF, 0xFE, 0xF1, 9, 9])) == 2
-    ch.feed_command_bytes(bytes([9] * 10))
-    assert ch.coeffs_q7().tolist() == [9] * 12
+    # split delivery, unknown bytes ignored; 0xA5 is the UART read request (imp/sequ2.vhd:216), 0x55 only starts
+    # the acquisition (new/command_control.vhd:58-60); the transport bytes are tracked (imp/sequ2.vhd:82-96)
+    assert ch.transport == 0xEF                                          # Ethernet after power-on
+    ev = ch.feed_command_bytes_ex(bytes([0x42, 0x55, 0xA5, 0xEF, 0xFE, 0xF1, 9, 9]))
+    assert (ev.n_start, ev.n_uart_request, ev.n_reset, ev.n_uploads, ev.control_changed, ev.transport) == (1, 1, 0, 0, 0, 0xFE)
+    ev = ch.feed_command_bytes_ex(bytes([9] * 10 + [0xA5]))
+    assert (ev.n_uploads, ev.control_changed, ev.n_uart_request) == (1, 1, 1)
+    assert ch.coeffs_q7().tolist() == [9] * 12 and ch.transport == 0xFE
+    assert ch.feed_command_bytes(bytes([0x55, 0xA5, 0xA5])) == 2          # legacy entry point: read requests only
     ch.feed_command_bytes(bytes([0x00]))
     assert ch.filter_mode == 0x00
-    ch.feed_command_bytes(bytes([0xFF]))                               # reset
+    ev = ch.feed_command_bytes_ex(bytes([0xFF]))                       # reset
     assert ch.filter_mode == 0xB1 and not ch.coeffs_q7().any()
+    assert ev.n_reset == 1 and ev.control_changed == 1 and ch.transport == 0xEF       # imp/sequ2.vhd:85-86
     # and the data path follows: custom mode with the GUI default upload
     ch.feed_command_bytes(wire + bytes([0xA1]))
     x = np.random.default_rng(5).integers(-2048, 2048, size=(2, N)).astype(np.int16)
