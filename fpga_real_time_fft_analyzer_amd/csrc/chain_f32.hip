@@ -21,6 +21,8 @@
 // The factor 1/2 of the split step is folded into the window table (exact in binary fp).
 #include "sa_common.hpp"
 #include "fft_regs.hpp"
+#include <atomic>
+#include <cstdlib>
 #include "../../include/specan.h"
 
 using safft::cf;
@@ -43,7 +45,7 @@ __device__ unsigned long long *g_sa_stamps = nullptr;
 #define SA_STAMP(i)                                                                        \
     do {                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        if (threadIdx.x == 0) {                                                            \
+        if (threadIdx.x == 0 && g_sa_stamps) {   /* never a store through a null table */  \
             unsigned long long c_;                                                         \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");     \
             g_sa_stamps[(size_t)blockIdx.x * 16 + (i)] = c_;                               \
@@ -78,8 +80,8 @@ __device__ __forceinline__ float lane_get(float v, int src_lane)
 }
 
 // z <- z + P * shifted(z): one Kogge-Stone level of the affine scan inside a row
-template <int N>
-__device__ __forceinline__ void scan_level(float &z1, float &z2, const float (&p)[4])
+template <int N, typename MatT>
+__device__ __forceinline__ void scan_level(float &z1, float &z2, const MatT &p)
 {
     const float u1 = row_shr<N>(z1), u2 = row_shr<N>(z2);
     z1 = __builtin_fmaf(p[0], u1, __builtin_fmaf(p[1], u2, z1));
@@ -117,15 +119,33 @@ __device__ __forceinline__ void store_nt(float *p, float a) { __builtin_nontempo
 // and multiplies by the window, which the host stored transposed (wint[g][t] = window[64t + 4g .. +3])
 // so that its loads are coalesced in this layout.
 // Thread t ends with d[j] = (x[64t + j], x[64t + 32 + j]) * window.
-template <bool WINGEN>
+// the LDS-DMA of round h (see stage_in_chunks): 8 x 1 KiB per wave, issued at raised priority so that the
+// requests leave ahead of the other workgroups' arithmetic
+__device__ __forceinline__ void dma_chunk_half(const float *__restrict__ xin, int h, unsigned char *smem, int lane, int wave)
+{
+    const int rl = lane >> 3;                                  // row inside the slab
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = wave * 8 + i;                            // slab: rows 8n .. 8n+7
+        const int r = 8 * n + rl;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const float *src = xin + r * 64 + h * 32 + lc * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// PREISSUED (persistent workgroups): round 0's DMA was requested earlier -- by the kernel prologue, or by the
+// previous frame just before its last group of output stores (`behind_stores` of them, issued after the DMA).
+template <bool WINGEN, bool PREISSUED>
 __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, const float4 *__restrict__ wint,
                                                 const SaIirLaneTab *__restrict__ lt, unsigned char *smem, int t,
-                                                v2f (&d)[32])
+                                                v2f (&d)[32], bool behind_stores = false)
 {
     const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
-    const int lane = t & 63, wave = t >> 6;
-    // per-lane byte offset of its 16-byte source column inside the slab of 8 chunk rows (256 B apart)
-    const int rl = lane >> 3;                                  // row inside the slab
+    const int lane = t & 63, wave = PREISSUED ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
     // WINGEN: the window a0 - a1 cos(theta n) evaluated in place (see stage_in_direct): W = G0 + P_h c_j + Q_h s_j
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
     float g0 = 0.f;
@@ -136,18 +156,17 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1) __syncthreads();          // round-0 readers are done with the image
-        __builtin_amdgcn_s_setprio(3);        // get the requests out ahead of the other workgroups' arithmetic
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = wave * 8 + i;                        // slab: rows 8n .. 8n+7
-            const int r = 8 * n + rl;
-            const int lc = (lane & 7) ^ ((r >> 1) & 7);
-            const float *src = xin + r * 64 + h * 32 + lc * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+        if (!(PREISSUED && h == 0)) {
+            dma_chunk_half(xin, h, smem, lane, wave);
+            __syncthreads();                  // waits for the DMA (vmcnt) and publishes the image
+        } else if (behind_stores) {
+            // The DMA is the OLDEST vector-memory traffic of this wave; the four 16-byte output stores of the
+            // previous frame's last group were issued after it.  vmcnt(4) = "all but the 4 youngest are done" =
+            // the DMA has landed while those stores may still be draining.
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();                      // waits for the DMA (vmcnt) and publishes the image
         const int sw = (t >> 1) & 7;
         const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
 #pragma unroll
@@ -254,7 +273,8 @@ __device__ __forceinline__ void tap_fma(v2f &n1, v2f &n2, const v2f tap, const v
 struct SecConsts {
     float pc0, pc1, pc2, pc3, mb0, mb1, mb2, mb3, b0, b1, b2, a1, a2, flags_bits;     // flags travel as raw bits
 };
-__device__ __forceinline__ SecConsts load_consts(const SaIirSecK &k)
+template <typename SecT>
+__device__ __forceinline__ SecConsts load_consts(const SecT &k)
 {
     return {k.pc[0], k.pc[1], k.pc[2], k.pc[3], k.mback[0], k.mback[1], k.mback[2], k.mback[3],
             k.c[0], k.c[1], k.c[2], k.c[3], k.c[4], __builtin_bit_cast(float, k.flags)};
@@ -273,8 +293,8 @@ __device__ __forceinline__ void pin_consts(const SecConsts &c)
 // 32 tap pairs, requested before the recursion so that they arrive under it).  Fused into one loop the 64 tap
 // registers are live from the top of the section and, with the section constants, exceed the 102 SGPRs a wave
 // has: the compiler then reloads them piecemeal, and every reload is an exposed scalar-load round trip.
-template <bool PREDICT_NEXT, bool UNIT>
-__device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, const SaIirSecK &knext, const SecConsts c,
+template <bool PREDICT_NEXT, bool UNIT, typename SecT>
+__device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const SecT &knext, const SecConsts c,
                                             SecConsts &cn, const float4 lanep, float2 *scr_s, int lane, int wave,
                                             v2f &z1, v2f &z2)
 {
@@ -363,8 +383,8 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SaIirSecK &k, co
 // All NSEC sections run unconditionally (the host pads shorter cascades with identity sections,
 // which are exact: y = 1*x + 0).  A run-time section count would carry the 64 data registers
 // through control-flow merges and cost ~190 register copies.
-template <int S, int NSEC, bool UNIT>
-__device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
+template <int S, int NSEC, bool UNIT, typename PlanT>
+__device__ __forceinline__ void iir_sections(v2f (&d)[32], const PlanT &ka, const SaIirLaneTab *__restrict__ lt,
                                              float2 *scr, int lane, int wave, v2f &z1, v2f &z2, const SecConsts c)
 {
     if constexpr (S < NSEC) {
@@ -376,8 +396,8 @@ __device__ __forceinline__ void iir_sections(v2f (&d)[32], const SaIirK &ka, con
     }
 }
 
-template <int NSEC, bool UNIT>
-__device__ __forceinline__ void iir_cascade(v2f (&d)[32], const SaIirK &ka, const SaIirLaneTab *__restrict__ lt,
+template <int NSEC, bool UNIT, typename PlanT>
+__device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const SaIirLaneTab *__restrict__ lt,
                                             float2 *scr, int t)
 {
     // predictor for the first section (later ones run after the previous section's recursion)
@@ -480,34 +500,36 @@ __device__ __forceinline__ int zpos_low(int q) { return zrow_pos(q, q >> 9); }
 __device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w >> 9)) & 7); }
 
 // ---------------------------------------------------------------------------------------------
-template <int NSEC, bool UNIT, int OUT, bool WINGEN>
-__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
-                                                                 void *__restrict__ out, int batch,
-                                                                 const float4 *__restrict__ winb,
-                                                                 const float4 *__restrict__ twT,
-                                                                 const float4 *__restrict__ twB,
-                                                                 const float2 *__restrict__ twC,
-                                                                 const SaIirLaneTab *__restrict__ lanetab,
-                                                                 const SaIirK ka)
+// One frame: window -> IIR -> FFT -> split -> store.  PERSIST: the workgroup loops over frames; round 0 of this
+// frame's stage-in was requested by the previous frame (or by the kernel prologue), and this frame requests the
+// next one's right after its last LDS read, ahead of its last group of split arithmetic and output stores.
+template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool PERSIST, typename PlanT>
+__device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *__restrict__ out, const int f,
+                                            const int f_next, const bool first_frame, unsigned char *smem,
+                                            const float4 *__restrict__ winb, const float4 *__restrict__ twT,
+                                            const float4 *__restrict__ twB, const float2 *__restrict__ twC,
+                                            const SaIirLaneTab *__restrict__ lanetab, const PlanT &ka)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf *ldc = reinterpret_cast<cf *>(smem);
     float2 *scr = reinterpret_cast<float2 *>(smem + kScrOff);
     cf *side = reinterpret_cast<cf *>(smem + kSideOff);
 
-    const int t = threadIdx.x;
+    int t = threadIdx.x;
+    // persistent form: an opaque copy of the thread index per frame, or every per-thread address of the body
+    // is hoisted out of the frame loop and spilled
+    if constexpr (PERSIST) asm volatile("" : "+v"(t));
     const int lane = t & 63;
-    const int wave = t >> 6;
+    const int wave = PERSIST ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
     const int lo = lane & 15;          // b in pass B, c in pass C
     const int kq = lane >> 4;
-    // one frame per workgroup: no loop => no loop-invariant address hoisting (which spilled)
-    const int f = blockIdx.x;
-    if (f >= batch) return;
     const float *xin = in + (size_t)f * SA_NPTS;
+#ifdef SA_STAMPS
+    const int sa_frame = f;
+#endif
     constexpr bool IIR = NSEC > 0;
     cf a[32];
 #ifdef SA_STAMPS
-    if (threadIdx.x == 0) g_sa_stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && g_sa_stamps) g_sa_stamps[(size_t)f * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
     SA_STAMP(0);
 
@@ -516,7 +538,8 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 #if defined(SA_STAGE_DIRECT)
         stage_in_direct<WINGEN>(xin, lanetab, t, d);
 #else
-        stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
+        stage_in_chunks<WINGEN, PERSIST>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d,
+                                         !first_frame);
 #endif
         SA_STAMP(1);
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
@@ -703,6 +726,15 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
                 zm[4] = side[0];
             }
             if (r == 1 && q0 == 0) zm[0] = side[0];
+            if constexpr (PERSIST && OUT == SA_OUT_MAG_FULL) {
+                if (r == 1 && jj == 1) {
+                    // the frame's last LDS read is done in every wave after this barrier: the image is free, and
+                    // the next frame's first half is requested ahead of this group's arithmetic and 4 stores
+                    lds_barrier();
+                    if (f_next >= 0) dma_chunk_half(in + (size_t)f_next * SA_NPTS, 0, smem, lane, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             cf R[5], I[5];
 #pragma unroll
             for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], R[e], I[e]);
@@ -715,13 +747,56 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
 #endif
     SA_STAMP(12);
 #ifdef SA_STAMPS
-    if (threadIdx.x == 0) {             // placement and wall-clock end (100 MHz counter, the same on every XCD)
-        g_sa_stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
-        g_sa_stamps[(size_t)blockIdx.x * 16 + 15] =
+    if (threadIdx.x == 0 && g_sa_stamps) {             // placement and wall-clock end (100 MHz counter, the same on every XCD)
+        g_sa_stamps[(size_t)f * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+        g_sa_stamps[(size_t)f * 16 + 15] =
             (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
             ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
     }
 #endif
+}
+
+template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool PERSIST>
+__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
+                                                                 void *__restrict__ out, int batch,
+                                                                 const float4 *__restrict__ winb,
+                                                                 const float4 *__restrict__ twT,
+                                                                 const float4 *__restrict__ twB,
+                                                                 const float2 *__restrict__ twC,
+                                                                 const SaIirLaneTab *__restrict__ lanetab,
+                                                                 const SaIirK ka)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int f = blockIdx.x;
+    if (f >= batch) return;
+    if constexpr (PERSIST) {
+        // grid = the workgroups the chip holds at once (4 per CU); workgroup b takes frames b, b + grid, ...
+        static_assert(NSEC > 0 && OUT == SA_OUT_MAG_FULL, "the persistent form is built for the headline kernels");
+        const int step = gridDim.x;
+        dma_chunk_half(in + (size_t)f * SA_NPTS, 0, smem, threadIdx.x & 63, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+        bool first = true;
+        for (;;) {
+            // Everything the body reads from the kernel arguments (2.9 KiB of plan constants, the table pointers)
+            // is loop-invariant: left visible, the compiler hoists hundreds of scalar loads and a dozen per-lane
+            // table loads out of the frame loop and spills them.  The body sees the arguments through an opaque
+            // copy of the kernel-argument segment pointer, refreshed per frame (layout: the parameter list above).
+            struct Args {
+                const float *in; void *out; int batch; int pad; const float4 *winb, *twT, *twB; const float2 *twC;
+                const SaIirLaneTab *lanetab; SaIirK ka;
+            };
+            typedef const Args __attribute__((address_space(4))) *ArgsPtr;
+            ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ap));
+            const int fn = f + step < ap->batch ? f + step : -1;
+            chain_frame<NSEC, UNIT, OUT, WINGEN, true>(ap->in, ap->out, f, fn, first, smem, ap->winb, ap->twT, ap->twB, ap->twC,
+                                                       ap->lanetab, ap->ka);
+            if (fn < 0) break;
+            f = fn;
+            first = false;
+        }
+    } else {
+        chain_frame<NSEC, UNIT, OUT, WINGEN, false>(in, out, f, -1, true, smem, winb, twT, twB, twC, lanetab, ka);
+    }
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
@@ -739,7 +814,7 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     if (f >= batch) return;
     v2f d[32];
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
-    stage_in_chunks<false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
+    stage_in_chunks<false, false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
     // Stage-out, the stage-in run backwards: each thread owns 64 consecutive samples, so storing straight
     // from the registers puts every lane of a store instruction into another 256-byte block (measured 5x
@@ -788,6 +863,21 @@ extern "C" int sa_debug_set_stamps(void *p)
 
 namespace {
 
+// Workgroups the device holds at once with this kernel's footprint: 4 per CU (35.6 KiB of LDS, 128 VGPRs).
+int resident_workgroups()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t pr;
+        v = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? 4 * pr.multiProcessorCount : 1024;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 template <int NSEC, bool UNIT>
 hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK &ka,
                        hipStream_t stream)
@@ -796,13 +886,28 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
     hipError_t e = hipSuccess;
 #define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
-        auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0)>                          \
-                              : chain_f32_kernel<NSEC, UNIT, OUTK, false>;                             \
+        auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0), false>                   \
+                              : chain_f32_kernel<NSEC, UNIT, OUTK, false, false>;                      \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
         hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, \
                            tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
+    // Persistent form (IIR kernels writing all 16384 magnitudes): once the batch exceeds what the chip holds at
+    // once, launch exactly that many workgroups and let each walk through its frames.
+    if constexpr (NSEC > 0) {
+        static const bool no_persist = std::getenv("SA_NO_PERSIST") != nullptr;      // A/B switch (tools/ab_libs.py)
+        const int resident = resident_workgroups();
+        if (out_kind == SA_OUT_MAG_FULL && !no_persist && batch > resident) {
+            auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, true, true>
+                                  : chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, false, true>;
+            e = set_lds(kern);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(resident), block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, tb.twB, tb.twC,
+                               tb.lanetab, ka);
+            return hipGetLastError();
+        }
+    }
     switch (out_kind) {
         case SA_OUT_MAG_FULL: SA_LAUNCH(SA_OUT_MAG_FULL); break;
         case SA_OUT_MAG_HALF: SA_LAUNCH(SA_OUT_MAG_HALF); break;

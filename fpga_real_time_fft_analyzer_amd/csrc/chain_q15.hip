@@ -12,8 +12,34 @@
 //                      (autosort) addressing so the result is in natural order; the arithmetic per
 //                      butterfly is exactly oracle/specan_oracle.c:or_fxfft16k.
 #include "sa_common.hpp"
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/specan.h"
+
+#ifdef SA_STAMPS
+// diagnostic build only: per wave {s_memrealtime at start, at end, HW_ID | XCC_ID << 32} (tools/q15_placement.py)
+__device__ unsigned long long *g_q15_stamps = nullptr;
+extern "C" int sa_debug_set_q15_stamps(void *p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_q15_stamps), &p, sizeof(p));
+}
+#define SA_Q15_STAMP_BEGIN(widx)                                                                      \
+    const unsigned long long sa_t0_ = __builtin_amdgcn_s_memrealtime();                               \
+    const int sa_widx_ = (widx)
+#define SA_Q15_STAMP_END()                                                                            \
+    do {                                                                                              \
+        if ((threadIdx.x & 63) == 0 && g_q15_stamps) {                                                \
+            g_q15_stamps[3 * sa_widx_ + 0] = sa_t0_;                                                  \
+            g_q15_stamps[3 * sa_widx_ + 1] = __builtin_amdgcn_s_memrealtime();                        \
+            g_q15_stamps[3 * sa_widx_ + 2] =                                                          \
+                (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |      \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+        }                                                                                             \
+    } while (0)
+#else
+#define SA_Q15_STAMP_BEGIN(widx) do {} while (0)
+#define SA_Q15_STAMP_END() do {} while (0)
+#endif
 
 namespace {
 
@@ -226,6 +252,7 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
     const int fr = lane >> 4;           // frame slot in this wave
     const int sec = lane & 15;          // section index (6..15 idle)
     const int f0 = blockIdx.x * kFramesPerWave;
+    SA_Q15_STAMP_BEGIN(blockIdx.x);
 
     if (prm.filter == SA_FILTER_NONE) {            // window only
         for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
@@ -294,6 +321,154 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
         __syncthreads();
         if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
     }
+    SA_Q15_STAMP_END();
+}
+
+// ------------------------------------------------------------------------------------------ IIR, Q7, second form
+// The FPGA-exact cascade again, reorganised around what bounds it: the recursion is serial in time, one wave per
+// SIMD, so the time per step is the wave's issue rate (and behind it the dependent-instruction latency) times
+// the instructions per step.  Against filter_q15_kernel above this form
+//   * takes the three feed-forward products straight from the LEFT NEIGHBOUR's output registers with
+//     v_mul_i32_i24_dpp (row_ror:1): no separate cross-lane move, no x[n-1] / x[n-2] history registers, and the
+//     path from the neighbour's y to this lane's y is three instructions instead of four;
+//   * feeds the input through the lanes the cascade leaves idle: lanes 9..15 and 0 of the 16-lane row are identity
+//     stages forming a shift register, refilled with eight samples by ONE 16-bit LDS read and one select every
+//     eight steps (the first form spent two instructions per step on the input);
+//   * writes each step as one asm block in a fixed order (older products first), so the DPP read of the register
+//     written by the previous step's last add always has three instructions in front of it (the hardware asks
+//     for two wait states; the compiler cannot see into an asm block and must not be relied on to pad);
+//   * runs four waves per workgroup (16 frames): the dispatcher places the waves of one workgroup on the four
+//     SIMDs of one CU, and 256 workgroups = one per CU at B = 4096, instead of 1024 one-wave workgroups that land
+//     two to a SIMD on part of the chip whenever the dispatcher's SIMD pointer is not where the previous launch
+//     of the same kernel left it (profiles/r2_q15_placement.txt: 673 us back to back, 943 us after anything else).
+// 9 vector instructions per step, none depending on the one before it (q7_step); lanes: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample
+// T - 8 at step T: every group of 8 steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input
+// shift register.  Arithmetic identical to BiqQ7::step (new/filter_iir_cust.vhd:96-117).
+constexpr int kV2Waves = 4;                       // waves per workgroup
+constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
+constexpr int kInPitch = kInRing + 8;
+
+// One step, software-pipelined by one: the block finishes y[n] and prepares the three terms of y[n+1] that do
+// not depend on it.  With h1 = y[n-1], h2 = y[n-2] (own lane; the DPP forms read the LEFT neighbour's) and
+// s2 = t(B1,x[n-1]) + t(B0,x[n-2]) - t(A0,y[n-2]) from the previous step:
+//     y[n] = s2 + t(B2, x[n]) - t(A1, y[n-1]);        s2' = t(B1, x[n]) + t(B0, x[n-1]) - t(A0, y[n-1]).
+// Only p4/p0 -> t -> y hang on the previous output (three instructions deep), the other five fill the gaps; no
+// instruction depends on its predecessor, and the DPP read of the register the previous step wrote at its 8th
+// instruction is this step's 3rd: three instructions in between (the hardware needs two wait states).
+#define SA_Q7_STEP(Y, H1, H2)                                                                                          \
+    "v_mad_i32_i24 %[p4], %[" H1 "], %[nA1], %[k]\n\t"                                                                 \
+    "v_mul_i32_i24_dpp %[p2], %[" H2 "], %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
+    "v_mul_i32_i24_dpp %[p0], %[" H1 "], %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
+    "v_mul_i32_i24_dpp %[p1], %[" H1 "], %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
+    "v_mad_i32_i24 %[p3], %[" H1 "], %[nA0], %[k]\n\t"                                                                 \
+    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
+    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
+    "v_add_u32_sdwa %[" Y "], %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"     \
+    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+
+// Eight steps in one block (one block = no compiler-inserted pad between steps): y[0..7] in: the lane's last eight
+// outputs (y[7] newest), out: the next eight.
+__device__ __forceinline__ void q7_steps8(int (&y)[8], int &s2, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
+{
+    int p0, p1, p2, p3, p4, t, u;
+    asm volatile(SA_Q7_STEP("y0", "y7", "y6") SA_Q7_STEP("y1", "y0", "y7") SA_Q7_STEP("y2", "y1", "y0")
+                     SA_Q7_STEP("y3", "y2", "y1") SA_Q7_STEP("y4", "y3", "y2") SA_Q7_STEP("y5", "y4", "y3")
+                         SA_Q7_STEP("y6", "y5", "y4") SA_Q7_STEP("y7", "y6", "y5") "s_nop 1"
+                 : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]),
+                   [y6] "+v"(y[6]), [y7] "+v"(y[7]), [s2] "+v"(s2), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2),
+                   [p3] "=&v"(p3), [p4] "=&v"(p4), [t] "=&v"(t), [u] "=&v"(u)
+                 : [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127));
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                                   int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tin_all[kV2Waves][kFramesPerWave][kInPitch];
+    __shared__ __attribute__((aligned(16))) int16_t ring_all[kV2Waves][kFramesPerWave][kRingPitch];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int16_t (*tin)[kInPitch] = tin_all[wave];
+    int16_t (*ring)[kRingPitch] = ring_all[wave];
+    const int fr = lane >> 4;           // frame slot in this wave
+    const int l16 = lane & 15;          // role inside the row
+    const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
+    if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
+    SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
+
+    // taps, pre-shifted by 9 (see BiqQ7); identity = (128 x) >> 7
+    int cB2 = 128 << 9, cB1 = 0, cB0 = 0, nA0 = 0, nA1 = 0;
+    if (l16 >= 1 && l16 <= 6) {
+        const int sec = l16 - 1;
+        const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
+        cB0 = c[0] << 9; cB1 = c[1] << 9; cB2 = c[2] << 9; nA0 = -(c[3] << 9); nA1 = -(c[4] << 9);
+    }
+    const int k127 = 127 << 9;
+    // input shift register: lanes 0, 15, 14, .., 9 take samples T0-1, T0, .., T0+6 at the start of a group
+    const int kin = (16 - l16) & 15;                       // 0..7 for the input lanes
+    const bool is_in = kin < 8;
+    const bool is_out = l16 == 8;
+    // zero the "tile before the first" (sample -1 must read as 0)
+    for (int c = lane; c < kFramesPerWave * kTile / 2; c += 64)
+        *reinterpret_cast<unsigned *>(&tin[c / (kTile / 2)][kTile + 2 * (c % (kTile / 2))]) = 0u;
+
+    int y[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the lane's last eight outputs, y[7] the newest
+    int s2 = 0;                                            // the prepared terms of the next step (zero history: 0)
+
+    Q15TileRegs pre;
+    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
+    for (int k = 0; k <= SA_NPTS / kTile; ++k) {           // one extra block drains the pipeline
+        const bool live = k < SA_NPTS / kTile;
+        if (live) {
+            // window the tile and put it into its half of the input ring
+            int16_t (*dst)[kInPitch] = tin;
+#pragma unroll
+            for (int i = 0; i < kFramesPerWave / 2; ++i) {
+                const int row = 2 * i + (lane >> 5);
+                const int col = (k & 1) * kTile + (lane & 31) * 8;
+                const unsigned xs[4] = {pre.x[i].x, pre.x[i].y, pre.x[i].z, pre.x[i].w};
+                const unsigned cs[4] = {pre.c[i].x, pre.c[i].y, pre.c[i].z, pre.c[i].w};
+                unsigned o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int a, b;
+                    if (prm.win_mode == SA_WIN_RTL_SIGNED) {
+                        a = win_rtl(lo16(xs[q]), lo16(cs[q]));
+                        b = win_rtl(hi16(xs[q]), hi16(cs[q]));
+                    } else {
+                        a = win_u16(lo16(xs[q]), lo16(cs[q]));
+                        b = win_u16(hi16(xs[q]), hi16(cs[q]));
+                    }
+                    o[q] = pack2(a, b);
+                }
+                *reinterpret_cast<uint4 *>(&dst[row][col]) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        wave_lds_sync();
+        // the next tile's HBM reads fly while this tile is being filtered
+        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
+        const int ngroups = live ? kTile / 8 : 1;
+        for (int g = 0; g < ngroups; ++g) {
+            const int T0 = k * kTile + 8 * g;
+            // refill the input shift register: one 16-bit LDS read per lane, one select
+            const int idx = (T0 - 1 + (is_in ? kin : 0)) & (kInRing - 1);
+            const int xin = tin[fr][idx];
+            y[7] = is_in ? xin : y[7];
+            q7_steps8(y, s2, cB2, cB1, cB0, nA0, nA1, k127);
+            // lane 8 holds samples T0 - 8 .. T0 - 1 (nothing valid before the first group)
+            if (is_out && T0 >= 8)
+                *reinterpret_cast<uint4 *>(&ring[fr][(T0 - 8) & (kRing - 1)]) =
+                    make_uint4(pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7]));
+        }
+        wave_lds_sync();
+        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
+    }
+    SA_Q15_STAMP_END();
 }
 
 // ------------------------------------------------------------------------------------------ FFT
@@ -448,10 +623,16 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
-    if (p.filter == SA_FILTER_WIDE)
+    static const bool old_form = std::getenv("SA_Q7_OLD") != nullptr;       // A/B switch for tools/ab_q15.py
+    if (p.filter == SA_FILTER_WIDE) {
         hipLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
-    else
+    } else if (p.filter == SA_FILTER_NONE || old_form) {
         hipLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
+    } else {
+        const int per_wg = kFramesPerWave * kV2Waves;
+        hipLaunchKernelGGL(filter_q7_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, in, out_time,
+                           batch, p, t.rom);
+    }
     return hipGetLastError();
 }
 
