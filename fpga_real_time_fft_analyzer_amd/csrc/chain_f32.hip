@@ -31,6 +31,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef SA_DMA_AUX
+#define SA_DMA_AUX 0          // cache policy bits of the input LDS-DMA (2 = nontemporal); A/B builds only
+#endif
 constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange image (4352 complex)
 constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 sections x 16 rows x float2
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
@@ -132,7 +135,7 @@ __device__ __forceinline__ void dma_chunk_half(const float *__restrict__ xin, in
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         const float *src = xin + r * 64 + h * 32 + lc * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
     }
     __builtin_amdgcn_s_setprio(0);
 }
@@ -157,7 +160,11 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
     for (int h = 0; h < 2; ++h) {
         if (h == 1) __syncthreads();          // round-0 readers are done with the image
         if (!(PREISSUED && h == 0)) {
-            dma_chunk_half(xin, h, smem, lane, wave);
+            int lane_d = lane;
+            // persistent form: derive this round's eight source addresses here, not ahead of round 0's window
+            // arithmetic where they would be computed early, kept across it and spilled
+            if constexpr (PREISSUED) asm volatile("" : "+v"(lane_d));
+            dma_chunk_half(xin, h, smem, lane_d, wave);
             __syncthreads();                  // waits for the DMA (vmcnt) and publishes the image
         } else if (behind_stores) {
             // The DMA is the OLDEST vector-memory traffic of this wave; the four 16-byte output stores of the
@@ -167,6 +174,9 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         } else {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        // nothing of the window arithmetic below may be scheduled above the wait (register-only instructions do
+        // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
+        __builtin_amdgcn_sched_barrier(0);
         const int sw = (t >> 1) & 7;
         const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
 #pragma unroll
@@ -546,29 +556,28 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
         // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
-        // imaginary parts (even / odd samples) live in two float planes: they sit in different
-        // register pairs of d[], and a 64-bit LDS store would need them copied into one pair first.
-        float *ldre = reinterpret_cast<float *>(smem);
-        float *ldim = ldre + 128 * 33;
+        // imaginary part (even / odd sample) sit in different register pairs of d[], so each complex value is
+        // stored as two dwords at adjacent addresses (one ds_write2_b32, no register copies); the reader then
+        // gets an aligned (re, im) pair per 8-byte read: half the LDS read instructions of two float planes.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             lds_barrier();
             if ((t >> 7) == h) {
-                const int base = 33 * (t & 127);
+                // written out: left to itself the compiler merges the two dword stores into one 64-bit store and
+                // copies the two halves into a register pair first (128 v_mov per thread)
+                const unsigned zw = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem) +
+                                    8u * 33u * (unsigned)(t & 127);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    ldre[base + j] = d[2 * j].x;
-                    ldim[base + j] = d[2 * j + 1].x;
-                    ldre[base + 16 + j] = d[2 * j].y;
-                    ldim[base + 16 + j] = d[2 * j + 1].y;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(zw), "v"(d[2 * j].x), "v"(d[2 * j + 1].x),
+                                 "i"(2 * j), "i"(2 * j + 1) : "memory");
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(zw), "v"(d[2 * j].y), "v"(d[2 * j + 1].y),
+                                 "i"(2 * (16 + j)), "i"(2 * (16 + j) + 1) : "memory");
                 }
             }
             lds_barrier();
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const int pos = 264 * m + 33 * (t >> 5) + (t & 31);
-                a[safft::brev(16 * h + m, 5)] = {ldre[pos], ldim[pos]};
-            }
+            for (int m = 0; m < 16; ++m) a[safft::brev(16 * h + m, 5)] = ldc[264 * m + 33 * (t >> 5) + (t & 31)];
         }
     } else {
         // No IIR: the frame goes HBM -> LDS in natural order (two rounds of 32 KiB, LDS-DMA), and the
@@ -731,7 +740,11 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
                     // the frame's last LDS read is done in every wave after this barrier: the image is free, and
                     // the next frame's first half is requested ahead of this group's arithmetic and 4 stores
                     lds_barrier();
-                    if (f_next >= 0) dma_chunk_half(in + (size_t)f_next * SA_NPTS, 0, smem, lane, wave);
+                    // an opaque copy of the lane index: without it the eight per-lane source offsets of the DMA are
+                    // shared with the stage-in's (common subexpressions), kept alive across the whole frame and spilled
+                    int lane_p = lane;
+                    asm volatile("" : "+v"(lane_p));
+                    if (f_next >= 0) dma_chunk_half(in + (size_t)f_next * SA_NPTS, 0, smem, lane_p, wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -893,12 +906,18 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
         hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, \
                            tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
-    // Persistent form (IIR kernels writing all 16384 magnitudes): once the batch exceeds what the chip holds at
-    // once, launch exactly that many workgroups and let each walk through its frames.
+    // Persistent form (IIR kernels writing all 16384 magnitudes): as many workgroups as the chip holds at once, each
+    // walking through its frames and requesting the next frame's first half ahead of its own last stores.
+    // OFF by default -- it is correct (bit-identical output) and measured SLOWER: 165 us against 133 us per 4096
+    // frames (profiles/r2_persistent_vs_dispatched.txt).  Workgroups that start together and never leave stay in
+    // lockstep: every frame then behaves like the first round of a launch, when all 1024 workgroups request their
+    // input at once and then all compute at once (first-round workgroups live 43 us, later ones 34 us).  The
+    // hardware dispatcher de-synchronises the workgroups for free by refilling slots as they drain.  Kept behind
+    // SA_PERSIST=1 so that the measurement can be repeated (tools/ab_libs.py lib.so:SA_PERSIST=1).
     if constexpr (NSEC > 0) {
-        static const bool no_persist = std::getenv("SA_NO_PERSIST") != nullptr;      // A/B switch (tools/ab_libs.py)
+        static const bool persist_on = std::getenv("SA_PERSIST") != nullptr;
         const int resident = resident_workgroups();
-        if (out_kind == SA_OUT_MAG_FULL && !no_persist && batch > resident) {
+        if (out_kind == SA_OUT_MAG_FULL && persist_on && batch > resident) {
             auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, true, true>
                                   : chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, false, true>;
             e = set_lds(kern);
