@@ -158,21 +158,26 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        if (h == 1) __syncthreads();          // round-0 readers are done with the image
+        // The image is WAVE-PRIVATE in this phase: wave w requests rows 64w .. 64w+63 (slabs 8w .. 8w+7) and its
+        // own threads are the only readers of those rows.  No workgroup barrier then: a wave waits for its own
+        // DMA (vmcnt) and, before overwriting the rows with round 1, for its own reads of round 0 (lgkmcnt).
+        // Three barriers fewer per frame; a wave delayed on its SIMD no longer holds the other three here.
+        if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(PREISSUED && h == 0)) {
             int lane_d = lane;
             // persistent form: derive this round's eight source addresses here, not ahead of round 0's window
             // arithmetic where they would be computed early, kept across it and spilled
             if constexpr (PREISSUED) asm volatile("" : "+v"(lane_d));
             dma_chunk_half(xin, h, smem, lane_d, wave);
-            __syncthreads();                  // waits for the DMA (vmcnt) and publishes the image
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (behind_stores) {
             // The DMA is the OLDEST vector-memory traffic of this wave; the four 16-byte output stores of the
             // previous frame's last group were issued after it.  vmcnt(4) = "all but the 4 youngest are done" =
-            // the DMA has landed while those stores may still be draining.
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            // the DMA has landed while those stores may still be draining.  (The barrier: the previous frame's
+            // readers of the image, other waves included, were done before the DMA was issued.)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // nothing of the window arithmetic below may be scheduled above the wait (register-only instructions do
         // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
