@@ -279,8 +279,27 @@ __device__ __forceinline__ void stage_in_direct(const float *__restrict__ xin, c
 // s_mov_b32 per tap, 192 per frame and wave).
 __device__ __forceinline__ void tap_fma(v2f &n1, v2f &n2, const v2f tap, const v2f y)
 {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(n1) : "s"(tap), "v"(y));
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(n2) : "s"(tap), "v"(y));
+    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+        : "+v"(n1), "+v"(n2) : "s"(tap), "v"(y));
+}
+
+// Eight taps in one statement (the compiler pads a wait state after every asm statement whose output the next one
+// reads; 32 single-tap statements = 32 pads per section).  Two accumulator pairs alternate: a dependent FMA every
+// fourth instruction.
+__device__ __forceinline__ void tap_fma8(v2f &n1a, v2f &n2a, v2f &n1b, v2f &n2b, const v2f (&tp)[8], const v2f (&y)[8])
+{
+#define SA_TAP(ACC1, ACC2, T, Y)                                                               \
+    "v_pk_fma_f32 %[" ACC1 "], %[" T "], %[" Y "], %[" ACC1 "] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
+    "v_pk_fma_f32 %[" ACC2 "], %[" T "], %[" Y "], %[" ACC2 "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+    asm(SA_TAP("a1", "a2", "t0", "y0") SA_TAP("b1", "b2", "t1", "y1") SA_TAP("a1", "a2", "t2", "y2")
+            SA_TAP("b1", "b2", "t3", "y3") SA_TAP("a1", "a2", "t4", "y4") SA_TAP("b1", "b2", "t5", "y5")
+                SA_TAP("a1", "a2", "t6", "y6") SA_TAP("b1", "b2", "t7", "y7") ""
+        : [a1] "+v"(n1a), [a2] "+v"(n2a), [b1] "+v"(n1b), [b2] "+v"(n2b)
+        : [t0] "s"(tp[0]), [t1] "s"(tp[1]), [t2] "s"(tp[2]), [t3] "s"(tp[3]), [t4] "s"(tp[4]), [t5] "s"(tp[5]), [t6] "s"(tp[6]),
+          [t7] "s"(tp[7]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4]), [y5] "v"(y[5]),
+          [y6] "v"(y[6]), [y7] "v"(y[7]));
+#undef SA_TAP
 }
 
 // The wave-uniform constants of one section, read one section ahead (while the previous section's loops run)
@@ -385,9 +404,10 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
         // four accumulators: each chain sees a dependent FMA every fourth instruction
         v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 32; j += 2) {
-            tap_fma(n1a, n2a, tp[j], d[j]);
-            tap_fma(n1b, n2b, tp[j + 1], d[j + 1]);
+        for (int j = 0; j < 32; j += 8) {
+            const v2f t8[8] = {tp[j], tp[j + 1], tp[j + 2], tp[j + 3], tp[j + 4], tp[j + 5], tp[j + 6], tp[j + 7]};
+            const v2f y8[8] = {d[j], d[j + 1], d[j + 2], d[j + 3], d[j + 4], d[j + 5], d[j + 6], d[j + 7]};
+            tap_fma8(n1a, n2a, n1b, n2b, t8, y8);
         }
         z1 = n1a + n1b;
         z2 = n2a + n2b;
@@ -419,9 +439,14 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const
     const SecConsts c0 = load_consts(ka.sec[0]);
     v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; j += 2) {
-        tap_fma(n1a, n2a, v2f{ka.m0[j][0], ka.m0[j][1]}, d[j]);
-        tap_fma(n1b, n2b, v2f{ka.m0[j + 1][0], ka.m0[j + 1][1]}, d[j + 1]);
+    for (int j = 0; j < 32; j += 8) {
+        v2f t8[8], y8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            t8[e] = v2f{ka.m0[j + e][0], ka.m0[j + e][1]};
+            y8[e] = d[j + e];
+        }
+        tap_fma8(n1a, n2a, n1b, n2b, t8, y8);
     }
     v2f z1 = n1a + n1b, z2 = n2a + n2b;
     pin_consts(c0);
@@ -434,9 +459,9 @@ __device__ __forceinline__ cf cmul_s(const cf a, const float2 wu)
 {
     const cf w = {wu.x, wu.y};
     cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));                 // a.x * (w.x, w.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                        // + a.y * (-w.y, w.x)
-        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                        // a.x * (w.x, w.y)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                      // + a.y * (-w.y, w.x)
+        : "=&v"(t), "=v"(r) : "v"(a), "s"(w));
     return r;
 }
 
@@ -453,12 +478,13 @@ __device__ __forceinline__ void split_eval(const cf zk, const cf zm, const cf w,
     const cf s = zk + zm;
     const cf d = zk - zm;
     // written out: the compiler assembles (w.y, -w.x) and (T.x, -T.x) with v_xor/v_mov pairs otherwise
+    // (one asm statement: no compiler pad between the dependent instructions)
     cf u, tw;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(u) : "v"(s), "v"(w));                  // s.y * w
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"                         // + d.x * (w.y, -w.x)
-        : "=v"(tw) : "v"(d), "v"(w), "v"(u));
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(R) : "v"(s), "v"(tw));    // s.x + (T.x, -T.x)
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(I) : "v"(d), "v"(tw));    // d.y + (T.y, -T.y)
+    asm("v_pk_mul_f32 %0, %4, %6 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                          // u = s.y * w
+        "v_pk_fma_f32 %1, %5, %6, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"                   // T = u + d.x * (w.y, -w.x)
+        "v_pk_add_f32 %2, %4, %1 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"                             // R = s.x + (T.x, -T.x)
+        "v_pk_add_f32 %3, %5, %1 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]"                                  // I = d.y + (T.y, -T.y)
+        : "=&v"(u), "=&v"(tw), "=&v"(R), "=v"(I) : "v"(s), "v"(d), "v"(w));
 }
 
 // Output of one group of bins k0..k0+4 (k0 = 4g).  The group evaluates five pairs so that all four

@@ -116,10 +116,12 @@ __host__ __device__ __forceinline__ void fft_dit(cf (&a)[R])
 __host__ __device__ __forceinline__ cf cmul(cf a, cf w)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // one statement for the pair: between two asm statements the compiler pads a wait state (s_nop) whenever the
+    // second reads the first's output, which the hardware does not need for an ordinary VALU dependency
     cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                 // a.x * (w.x, w.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                        // + a.y * (-w.y, w.x)
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                        // a.x * (w.x, w.y)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                      // + a.y * (-w.y, w.x)
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(w));
     return r;
 #else
     const cf t = {a.x * w.x, a.x * w.y};

@@ -56,7 +56,11 @@ class FrameCutter:
 
 class DeviceFeeder:
     """Double-buffered host -> device mover: ``feed(batch_iter)`` yields device tensors [B,16384] int16
-    while the next batch is already in flight on a side stream."""
+    while the next batch is already in flight on a side stream.
+
+    Two pinned staging buffers, two device buffers, and FOUR events created once (a "copied" and a
+    "consumed" event per slot): creating and destroying HIP events per batch stalled the host for 50-100 ms
+    every dozen batches (profiles/r2_ingest.txt)."""
 
     def __init__(self, device: torch.device | int = 0, max_batch: int = 256):
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -64,30 +68,37 @@ class DeviceFeeder:
         self._pinned = [torch.empty((max_batch, N), dtype=torch.int16).pin_memory() for _ in range(2)]
         self._dev = [torch.empty((max_batch, N), dtype=torch.int16, device=self.device) for _ in range(2)]
         self._copy_stream = torch.cuda.Stream(self.device)
+        self._copied = [torch.cuda.Event() for _ in range(2)]      # slot's host->device copy has run
+        self._consumed = [torch.cuda.Event() for _ in range(2)]    # slot's consumer work has been enqueued and run
+        self._used = [False, False]
 
     def feed(self, batches: Iterable[np.ndarray]) -> Iterator[torch.Tensor]:
-        ev: list[Optional[torch.cuda.Event]] = [None, None]
-        pend = None
+        cur = torch.cuda.current_stream(self.device)
+        pend = None                                             # (slot, n_frames) handed out next
         for i, b in enumerate(batches):
             b = np.ascontiguousarray(b, np.int16).reshape(-1, N)
-            if b.shape[0] > self.max_batch:
+            n = b.shape[0]
+            if n > self.max_batch:
                 raise ValueError("batch larger than max_batch")
             slot = i & 1
-            if ev[slot] is not None:
-                ev[slot].synchronize()                      # slot's previous consumer is done
-            self._pinned[slot][:b.shape[0]].copy_(torch.from_numpy(b))
+            if self._used[slot]:
+                self._consumed[slot].synchronize()              # the slot's previous consumer is done with it
+            self._pinned[slot][:n].copy_(torch.from_numpy(b))
             with torch.cuda.stream(self._copy_stream):
-                self._dev[slot][:b.shape[0]].copy_(self._pinned[slot][:b.shape[0]], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(self._copy_stream)
+                self._dev[slot][:n].copy_(self._pinned[slot][:n], non_blocking=True)
+                self._copied[slot].record(self._copy_stream)
             if pend is not None:
-                yield pend
-                ev[(i - 1) & 1] = torch.cuda.Event()
-                ev[(i - 1) & 1].record(torch.cuda.current_stream(self.device))
-            torch.cuda.current_stream(self.device).wait_event(done)
-            pend = self._dev[slot][:b.shape[0]]
+                ps, pn = pend
+                yield self._dev[ps][:pn]                        # the consumer enqueues its work on `cur` here
+                self._consumed[ps].record(cur)
+                self._used[ps] = True
+            cur.wait_event(self._copied[slot])
+            pend = (slot, n)
         if pend is not None:
-            yield pend
+            ps, pn = pend
+            yield self._dev[ps][:pn]
+            self._consumed[ps].record(cur)
+            self._used[ps] = True
 
 
 def udp_emit(frame_bytes: bytes, addr: tuple[str, int], sock: Optional[socket.socket] = None,

@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes for the fused float kernel (run on the GPU box through gpurun).  usage: pmc_profile.sh MODE TAG
+# PMC passes for the fused float kernel, or the Q15 kernels with MODE = q15 (run on the GPU box through gpurun).
+# usage: pmc_profile.sh MODE TAG
 # Counters go in separate passes (SQ 8 slots, TCC 4: FETCH_SIZE takes 3, WRITE_SIZE 2).
 MODE=${1:-0xA1}; TAG=${2:-pmc}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

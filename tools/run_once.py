@@ -10,10 +10,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
 
-mode = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0xA1
+q15 = len(sys.argv) > 1 and sys.argv[1] == "q15"
+mode = 0x00 if q15 else (int(sys.argv[1], 0) if len(sys.argv) > 1 else 0xA1)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 ch = SpectrumChain(0)
+if q15:                                           # config 4: integer cascade + integer FFT
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    xq = torch.randint(-2048, 2048, (B, 16384), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
+    oq = torch.empty((B, 16384, 2), dtype=torch.int16, device="cuda")
+    ch.reserve(B)
+    ch.set_filter_mode(0x00)
+    for _ in range(iters):
+        ch.process_q15(xq, out=oq)
+    torch.cuda.synchronize()
+    sys.exit(0)
 ch.load_sos(np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"])
 ch.set_filter_mode(mode)
 gen = torch.Generator(device="cuda").manual_seed(1)
