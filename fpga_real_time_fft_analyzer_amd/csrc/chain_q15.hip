@@ -476,16 +476,25 @@ constexpr int kFftThreads = 256;
 
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 
+// (sat16(lo), sat16(hi)) as one packed dword: v_cvt_pk_i16_i32 saturates and packs in ONE instruction
+// (two v_med3_i32, an and and a shift-or otherwise -- a seventh of the kernel's vector instructions)
+__device__ __forceinline__ unsigned sat_pack2(int lo, int hi)
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 r = __builtin_amdgcn_cvt_pk_i16(lo, hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // y = sat16((u * w) >> 15), truncation; e == 0 is an exact pass-through (SA-FXFFT-1)
 __device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool unity)
 {
     // (sum of four int16) >> 2 lies in [-32768, 32767] already: the saturation of the spec cannot trigger on a
     // pass-through, only after a twiddle product (|u w| >> 15 reaches 65534)
-    if (unity) return pack2(ur, ui);
+    if (unity) return sat_pack2(ur, ui);          // in range: the saturation is the identity, the pack is what is wanted
     const int wr = lo16(w), wi = hi16(w);
     const int pr = (ur * wr - ui * wi) >> 15;
     const int pi = (ur * wi + ui * wr) >> 15;
-    return pack2(sat16(pr), sat16(pi));
+    return sat_pack2(pr, pi);
 }
 
 // one radix-4 DIF butterfly of SA-FXFFT-1 on packed (re, im) int16 pairs: 32-bit sums, >> 2 (truncation),
@@ -497,7 +506,7 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
     const int cr = lo16(c), ci = hi16(c), dr = lo16(d), di = hi16(d);
     const int sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;      // a +/- c
     const int ur = br + dr, ui = bi + di, vr = br - dr, vi = bi - di;      // b +/- d
-    o[0] = pack2((sr + ur) >> 2, (si + ui) >> 2);                          // in range by construction, see fx_twiddle
+    o[0] = sat_pack2((sr + ur) >> 2, (si + ui) >> 2);                      // in range by construction, see fx_twiddle
     o[1] = fx_twiddle((tr + vi) >> 2, (ti - vr) >> 2, w1, unity);          // a - i b - c + i d
     o[2] = fx_twiddle((sr - ur) >> 2, (si - ui) >> 2, w2, unity);
     o[3] = fx_twiddle((tr - vi) >> 2, (ti + vr) >> 2, w3, unity);          // a + i b - c - i d

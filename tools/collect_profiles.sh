@@ -17,7 +17,7 @@ with open(f"{out}/{tag}_kernel_stats.csv", "w") as fh:
     w = csv.writer(fh)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
-        w.writerow([r["Name"].split("(")[0].replace("void (anonymous namespace)::", ""), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+        w.writerow([r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 PY
 # 2. un-profiled bench line (with the CPU baseline)
 python3 bench.py --extras > $OUT/${TAG}_bench.json 2> $OUT/bench.err

@@ -19,6 +19,9 @@ sys.path.insert(0, ROOT)
 from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
 from fpga_real_time_fft_analyzer_amd.ingest import DeviceFeeder  # noqa: E402
 
+# the box gives this job 16 CPUs of a 256-core host: torch's default intra-op pool (one thread per visible core)
+# stalls the staging copy for 50-100 ms every dozen batches
+torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
 N = 16384
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 32

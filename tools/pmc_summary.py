@@ -12,9 +12,10 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if "chain_f32" not in k and "q15" not in k:
+            if "chain_f32" not in k and "q15" not in k and "q7" not in k:
                 continue
-            acc[k.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     print("==", k)
     for c in sorted(d):
