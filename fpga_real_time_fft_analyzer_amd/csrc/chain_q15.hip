@@ -63,6 +63,15 @@ __device__ __forceinline__ int win_u16(int x, int c)
 }
 
 __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+// (sat16(lo), sat16(hi)) as one packed dword: v_cvt_pk_i16_i32 saturates and packs in ONE instruction
+// (two v_med3_i32, an and and a shift-or otherwise -- a seventh of the kernel's vector instructions)
+__device__ __forceinline__ unsigned sat_pack2(int lo, int hi)
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 r = __builtin_amdgcn_cvt_pk_i16(lo, hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 __device__ __forceinline__ int lo16(unsigned v) { return (int)(short)(v & 0xFFFFu); }
 __device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
 
@@ -452,18 +461,26 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         // the next tile's HBM reads fly while this tile is being filtered
         if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
         const int ngroups = live ? kTile / 8 : 1;
+        // refill values of the input shift register (one 16-bit LDS read per lane and group), requested one group
+        // ahead: the read of group g+1 travels under the 72 instructions of group g instead of being waited for
+        // (profiles/r2_pmc_q15.txt: the wave sat in s_waitcnt 27 % of its life).  Only the first group of a tile
+        // waits: its samples arrived with the tile itself.
+        const int16_t *trow = &tin[fr][0];
+        const int koff = is_in ? kin - 1 : -1;
+        int xin = trow[(k * kTile + koff) & (kInRing - 1)];
         for (int g = 0; g < ngroups; ++g) {
             const int T0 = k * kTile + 8 * g;
-            // refill the input shift register: one 16-bit LDS read per lane, one select
-            const int idx = (T0 - 1 + (is_in ? kin : 0)) & (kInRing - 1);
-            const int xin = tin[fr][idx];
+            // the next group's refill (the last group of a tile re-reads a valid slot: its value is not used)
+            const int xin_next = trow[(T0 + (g + 1 < ngroups ? 8 : 0) + koff) & (kInRing - 1)];
             y[7] = is_in ? xin : y[7];
 #pragma unroll
             for (int e = 0; e < 8; ++e) q7_step(y[e], s2, y[(e + 7) & 7], y[(e + 6) & 7], cB2, cB1, cB0, nA0, nA1, k127);
-            // lane 8 holds samples T0 - 8 .. T0 - 1 (nothing valid before the first group)
+            // lane 8 holds samples T0 - 8 .. T0 - 1 (nothing valid before the first group); the values are
+            // sign-extended 16-bit numbers: the saturating pack is exact and one instruction per pair
             if (is_out && T0 >= 8)
                 *reinterpret_cast<uint4 *>(&ring[fr][(T0 - 8) & (kRing - 1)]) =
-                    make_uint4(pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7]));
+                    make_uint4(sat_pack2(y[0], y[1]), sat_pack2(y[2], y[3]), sat_pack2(y[4], y[5]), sat_pack2(y[6], y[7]));
+            xin = xin_next;
         }
         wave_lds_sync();
         if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
@@ -475,15 +492,6 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
 constexpr int kFftThreads = 256;
 
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
-
-// (sat16(lo), sat16(hi)) as one packed dword: v_cvt_pk_i16_i32 saturates and packs in ONE instruction
-// (two v_med3_i32, an and and a shift-or otherwise -- a seventh of the kernel's vector instructions)
-__device__ __forceinline__ unsigned sat_pack2(int lo, int hi)
-{
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 r = __builtin_amdgcn_cvt_pk_i16(lo, hi);
-    return __builtin_bit_cast(unsigned, r);
-}
 
 // y = sat16((u * w) >> 15), truncation; e == 0 is an exact pass-through (SA-FXFFT-1)
 __device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool unity)
