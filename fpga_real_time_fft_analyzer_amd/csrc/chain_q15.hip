@@ -225,18 +225,19 @@ __device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, c
 
 template <int PITCH>
 __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const int16_t (*src)[PITCH], int src_col,
-                                               int f0, int batch, int n0, int lane)
+                                               int f0, int batch, int n0, int lane, int col_mask = 0x7fffffff)
 {
 #pragma unroll
     for (int i = 0; i < kFramesPerWave / 2; ++i) {
         const int row = 2 * i + (lane >> 5);
         const int col = (lane & 31) * 8;
         const int f = f0 + row;
+        const int sc = (src_col + col) & col_mask;      // 8-sample chunks: a ring wraps between chunks only
         uint4 ov;
-        ov.x = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 0]);
-        ov.y = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 2]);
-        ov.z = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 4]);
-        ov.w = *reinterpret_cast<const unsigned *>(&src[row][src_col + col + 6]);
+        ov.x = *reinterpret_cast<const unsigned *>(&src[row][sc + 0]);
+        ov.y = *reinterpret_cast<const unsigned *>(&src[row][sc + 2]);
+        ov.z = *reinterpret_cast<const unsigned *>(&src[row][sc + 4]);
+        ov.w = *reinterpret_cast<const unsigned *>(&src[row][sc + 6]);
         if (f < batch) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
     }
 }
@@ -357,35 +358,164 @@ constexpr int kV2Waves = 4;                       // waves per workgroup
 constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
 constexpr int kInPitch = kInRing + 8;
 
-// One step, software-pipelined by one: the block finishes y[n] and prepares the three terms of y[n+1] that do
-// not depend on it.  With h1 = y[n-1], h2 = y[n-2] (own lane; the DPP forms read the LEFT neighbour's) and
-// s2 = t(B1,x[n-1]) + t(B0,x[n-2]) - t(A0,y[n-2]) from the previous step:
-//     y[n] = s2 + t(B2, x[n]) - t(A1, y[n-1]);        s2' = t(B1, x[n]) + t(B0, x[n-1]) - t(A0, y[n-1]).
-// Only p4/p0 -> t -> y hang on the previous output (three instructions deep), the other five fill the gaps; no
-// instruction depends on its predecessor, and the DPP read of the register the previous step wrote at its 8th
-// instruction is this step's 3rd: three instructions in between (the hardware needs two wait states).
-#define SA_Q7_STEP(Y, H1, H2)                                                                                          \
-    "v_mad_i32_i24 %[p4], %[" H1 "], %[nA1], %[k]\n\t"                                                                 \
-    "v_mul_i32_i24_dpp %[p2], %[" H2 "], %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
-    "v_mul_i32_i24_dpp %[p0], %[" H1 "], %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
-    "v_mul_i32_i24_dpp %[p1], %[" H1 "], %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
-    "v_mad_i32_i24 %[p3], %[" H1 "], %[nA0], %[k]\n\t"                                                                 \
-    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
-    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
+// One block = one time step, written in the cyclic order the issue logic likes best.  With x = the LEFT neighbour's
+// output (read in place by the DPP forms), y = the lane's own, and per step
+//     y[n] = s2 + t,    t = t(B2, x[n]) - t(A1, y[n-1]),    s2 = t(B1, x[n-1]) + t(B0, x[n-2]) - t(A0, y[n-2])
+// the block FIRST finishes y[n] from the t and s2 the previous block prepared (H), then starts everything of
+// y[n+1] and y[n+2] that hangs on it:
+//     H  y   = (int16)(s2 + t)                 G  u  = hi(p1) + hi(p2)        (terms of the block before)
+//     B  p2  = x[n-1] * B0   (dpp)             C  p0 = x[n] * B2   (dpp; the neighbour's H is 3 instructions old)
+//     A  p4  = y * -A1 + k                     I  s2 = u + hi(p3)
+//     D  p1  = x[n] * B1     (dpp)             F  t  = hi(p0) + hi(p4)
+//     E  p3  = y * -A0 + k
+// No instruction reads a register written by either of the two instructions in front of it except F -> H of the
+// next block (one in between); the DPP read of the y just written has two instructions in between, which is what
+// the hardware asks for (the compiler cannot see into an asm block and must not be relied on to pad).
+// tools/ubench/q7_step_rate.hip times these nine instructions alone, one wave per SIMD: 19.5 ns per step in this
+// order, 24.1 ns in the order A B C D E F G H I (y finished second to last, its first reader one instruction later).
+#define SA_Q7_BLOCK(Y, H1)                                                                                             \
     "v_add_u32_sdwa %[" Y "], %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"     \
-    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
+    "v_mul_i32_i24_dpp %[p2], %[" H1 "], %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                              \
+    "v_mul_i32_i24_dpp %[p0], %[" Y "], %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                               \
+    "v_mad_i32_i24 %[p4], %[" Y "], %[nA1], %[k]\n\t"                                                                  \
+    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"         \
+    "v_mul_i32_i24_dpp %[p1], %[" Y "], %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                               \
+    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"        \
+    "v_mad_i32_i24 %[p3], %[" Y "], %[nA0], %[k]"
 
-// One asm block per step (measured: eight steps merged into one block, which saves the compiler's one-cycle pad
-// between blocks, ran 5 % slower -- 648 against 614 us -- so the steps stay separate).
-__device__ __forceinline__ void q7_step(int &y, int &s2, int y7, int y6, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
+// what one block hands to the next (zero history = all zero: hi(k) = 0)
+struct Q7Carry {
+    int p0, p1, p2, p3, p4, t, u, s2;
+};
+
+__device__ __forceinline__ void q7_block(int &y, Q7Carry &c, int y7, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
 {
-    int p0, p1, p2, p3, p4, t, u, y0;
-    asm volatile(SA_Q7_STEP("y0", "y7", "y6")
-                 : [y0] "=&v"(y0), [s2] "+v"(s2), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4),
-                   [t] "=&v"(t), [u] "=&v"(u)
-                 : [y7] "v"(y7), [y6] "v"(y6), [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1),
-                   [k] "s"(k127));
+    int y0;
+    asm volatile(SA_Q7_BLOCK("y0", "y7")
+                 : [y0] "=&v"(y0), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p1] "+v"(c.p1), [p2] "+v"(c.p2), [p3] "+v"(c.p3),
+                   [p4] "+v"(c.p4), [t] "+v"(c.t), [u] "+v"(c.u)
+                 : [y7] "v"(y7), [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127));
     y = y0;
+}
+
+typedef unsigned q7_u4 __attribute__((ext_vector_type(4)));
+
+// 16-byte LDS store by the lanes of `mask` only, without a branch around it (the compiler's form is a
+// saveexec / skip-branch / restore triple laid out of line: two taken branches per eight steps)
+__device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsigned long long mask)
+{
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "ds_write_b128 %[a], %[d]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved) : [m] "s"(mask), [a] "v"(addr), [d] "v"(v) : "memory", "scc");
+}
+
+// The 32 groups of a tile as ONE asm statement.  A lone wave issues at most one instruction per turn of its SIMD
+// and stalls whole turns; which turns are lost depends on where the 8-byte instructions lie relative to the
+// instruction fetch (tools/ubench/q7_nop_sweep.py: the same nine instructions run 19.4, 21.7 or 24.1 ns per step
+// depending on a 4-byte s_nop in front of them or between them), so the loop is pinned: 64-byte aligned, nothing of
+// the compiler's inside it, `s_nop 0` where SA_Q7_NOPS (bit p = after instruction p of the block, order
+// H G B C A I D F E) says.  Per group: select the refill into t, request the next refill (16-bit LDS read, used
+// one group later: lgkmcnt(1) = everything but the store behind it), eight blocks, pack lane 8's eight outputs and
+// store them under an exec mask (restored five instructions before the next DPP read, as the hardware asks).
+#ifndef SA_Q7_NOPS
+#define SA_Q7_NOPS 0x080
+#endif
+#if SA_Q7_NOPS & 0x001
+#define SA_N0 "s_nop 0\n\t"
+#else
+#define SA_N0
+#endif
+#if SA_Q7_NOPS & 0x002
+#define SA_N1 "s_nop 0\n\t"
+#else
+#define SA_N1
+#endif
+#if SA_Q7_NOPS & 0x004
+#define SA_N2 "s_nop 0\n\t"
+#else
+#define SA_N2
+#endif
+#if SA_Q7_NOPS & 0x008
+#define SA_N3 "s_nop 0\n\t"
+#else
+#define SA_N3
+#endif
+#if SA_Q7_NOPS & 0x010
+#define SA_N4 "s_nop 0\n\t"
+#else
+#define SA_N4
+#endif
+#if SA_Q7_NOPS & 0x020
+#define SA_N5 "s_nop 0\n\t"
+#else
+#define SA_N5
+#endif
+#if SA_Q7_NOPS & 0x040
+#define SA_N6 "s_nop 0\n\t"
+#else
+#define SA_N6
+#endif
+#if SA_Q7_NOPS & 0x080
+#define SA_N7 "s_nop 0\n\t"
+#else
+#define SA_N7
+#endif
+#if SA_Q7_NOPS & 0x100
+#define SA_N8 "s_nop 0\n\t"
+#else
+#define SA_N8
+#endif
+#define SA_Q7_TBLOCK(Y, H1)                                                                                            \
+    "v_add_u32_sdwa %[" Y "], %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t" SA_N0 \
+    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N1  \
+    "v_mul_i32_i24_dpp %[p2], %[" H1 "], %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N2                        \
+    "v_mul_i32_i24_dpp %[p0], %[" Y "], %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N3                         \
+    "v_mad_i32_i24 %[p4], %[" Y "], %[nA1], %[k]\n\t" SA_N4                                                            \
+    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" SA_N5   \
+    "v_mul_i32_i24_dpp %[p1], %[" Y "], %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N6                         \
+    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N7  \
+    "v_mad_i32_i24 %[p3], %[" Y "], %[nA0], %[k]\n\t" SA_N8
+#define SA_Q7_TGROUP(RD_OFF, WR_OFF)                                                                                   \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                         \
+    "v_cndmask_b32_e64 %[t], %[t], %[xin], %[inm]\n\t"                                                                 \
+    "ds_read_u16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
+    SA_Q7_TBLOCK("y0", "y7") SA_Q7_TBLOCK("y1", "y0") SA_Q7_TBLOCK("y2", "y1") SA_Q7_TBLOCK("y3", "y2")                \
+    SA_Q7_TBLOCK("y4", "y3") SA_Q7_TBLOCK("y5", "y4") SA_Q7_TBLOCK("y6", "y5") SA_Q7_TBLOCK("y7", "y6")                \
+    "v_cvt_pk_i16_i32 v60, %[y0], %[y1]\n\t"                                                                           \
+    "v_cvt_pk_i16_i32 v61, %[y2], %[y3]\n\t"                                                                           \
+    "v_cvt_pk_i16_i32 v62, %[y4], %[y5]\n\t"                                                                           \
+    "v_cvt_pk_i16_i32 v63, %[y6], %[y7]\n\t"                                                                           \
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
+    "ds_write_b128 %[ra], v[60:63] offset:" WR_OFF "\n\t"                                                              \
+    "s_mov_b64 exec, %[sv]\n\t"
+
+// xa: LDS byte address of the lane's refill slot of the tile's first group; ra: of the ring slot of its outputs
+__device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, unsigned ra, unsigned long long in_mask,
+                                        unsigned long long out_mask, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
+{
+    int xin, cnt = kTile / 32;
+    unsigned long long saved;
+    asm volatile(
+        "ds_read_u16 %[xin], %[xa]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"                      // first group: nothing in flight, lgkmcnt(1) passes
+        ".p2align 6\n"
+        "1:\n\t"
+        SA_Q7_TGROUP("16", "0") SA_Q7_TGROUP("32", "16") SA_Q7_TGROUP("48", "32") SA_Q7_TGROUP("64", "48")
+        "v_add_u32 %[xa], 64, %[xa]\n\t"
+        "v_add_u32 %[ra], 64, %[ra]\n\t"
+        "s_add_i32 %[cnt], %[cnt], -1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]),
+          [y7] "+v"(y[7]), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p1] "+v"(c.p1), [p2] "+v"(c.p2), [p3] "+v"(c.p3), [p4] "+v"(c.p4),
+          [t] "+v"(c.t), [u] "+v"(c.u), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt), [sv] "=&s"(saved)
+        : [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask),
+          [outm] "s"(out_mask)
+        : "memory", "scc", "v60", "v61", "v62", "v63");
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -417,16 +547,31 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         cB0 = c[0] << 9; cB1 = c[1] << 9; cB2 = c[2] << 9; nA0 = -(c[3] << 9); nA1 = -(c[4] << 9);
     }
     const int k127 = 127 << 9;
-    // input shift register: lanes 0, 15, 14, .., 9 take samples T0-1, T0, .., T0+6 at the start of a group
+    // input shift register: lanes 0, 15, 14, .., 9 take samples T0, T0+1, .., T0+7 as their y[T0] (through t: they
+    // are identity stages, s2 = 0) at the start of a group
     const int kin = (16 - l16) & 15;                       // 0..7 for the input lanes
     const bool is_in = kin < 8;
-    const bool is_out = l16 == 8;
-    // zero the "tile before the first" (sample -1 must read as 0)
-    for (int c = lane; c < kFramesPerWave * kTile / 2; c += 64)
-        *reinterpret_cast<unsigned *>(&tin[c / (kTile / 2)][kTile + 2 * (c % (kTile / 2))]) = 0u;
+    const unsigned long long out_mask = 0x0100010001000100ull;   // lane 8 of every row
+    const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
+    const uint16_t *xrow = reinterpret_cast<const uint16_t *>(&tin[fr][0]) + (is_in ? kin : 0);
+    const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const uint16_t *)xrow;
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)(&ring[fr][0]);
 
-    int y[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the lane's last eight outputs, y[7] the newest
-    int s2 = 0;                                            // the prepared terms of the next step (zero history: 0)
+    int y[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the lane's last eight outputs
+    Q7Carry c = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // eight steps in the compiler's hands (the drain group only; the tiles run q7_tile).  Lane 8 then holds
+    // samples T0 - 8 .. T0 - 1; sample m lives in ring slot (m + 8) mod kRing, so that the groups of one tile store
+    // to consecutive slots (the first group of the frame stores eight zeros into slots nobody reads).  The values
+    // are sign-extended 16-bit numbers: the saturating pack is exact and one instruction per pair.
+    auto group = [&](int T0, int xin) {
+        c.t = is_in ? xin : c.t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q7_block(y[e], c, y[(e + 7) & 7], cB2, cB1, cB0, nA0, nA1, k127);
+        q7_u4 v;
+        v.x = sat_pack2(y[0], y[1]); v.y = sat_pack2(y[2], y[3]); v.z = sat_pack2(y[4], y[5]); v.w = sat_pack2(y[6], y[7]);
+        lds_store16_masked(ring_addr + 2 * (T0 & (kRing - 1)), v, out_mask);
+    };
 
     Q15TileRegs pre;
     q15_load_tile(in, rom, f0, batch, 0, lane, pre);
@@ -460,30 +605,15 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         wave_lds_sync();
         // the next tile's HBM reads fly while this tile is being filtered
         if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
-        const int ngroups = live ? kTile / 8 : 1;
-        // refill values of the input shift register (one 16-bit LDS read per lane and group), requested one group
-        // ahead: the read of group g+1 travels under the 72 instructions of group g instead of being waited for
-        // (profiles/r2_pmc_q15.txt: the wave sat in s_waitcnt 27 % of its life).  Only the first group of a tile
-        // waits: its samples arrived with the tile itself.
-        const int16_t *trow = &tin[fr][0];
-        const int koff = is_in ? kin - 1 : -1;
-        int xin = trow[(k * kTile + koff) & (kInRing - 1)];
-        for (int g = 0; g < ngroups; ++g) {
-            const int T0 = k * kTile + 8 * g;
-            // the next group's refill (the last group of a tile re-reads a valid slot: its value is not used)
-            const int xin_next = trow[(T0 + (g + 1 < ngroups ? 8 : 0) + koff) & (kInRing - 1)];
-            y[7] = is_in ? xin : y[7];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q7_step(y[e], s2, y[(e + 7) & 7], y[(e + 6) & 7], cB2, cB1, cB0, nA0, nA1, k127);
-            // lane 8 holds samples T0 - 8 .. T0 - 1 (nothing valid before the first group); the values are
-            // sign-extended 16-bit numbers: the saturating pack is exact and one instruction per pair
-            if (is_out && T0 >= 8)
-                *reinterpret_cast<uint4 *>(&ring[fr][(T0 - 8) & (kRing - 1)]) =
-                    make_uint4(sat_pack2(y[0], y[1]), sat_pack2(y[2], y[3]), sat_pack2(y[4], y[5]), sat_pack2(y[6], y[7]));
-            xin = xin_next;
-        }
+        // refill values of the input shift register: one 16-bit LDS read per lane and group, requested one group
+        // ahead (profiles/r2_pmc_q15.txt: waiting for it, the wave sat in s_waitcnt 27 % of its life).  The last
+        // group of a tile requests the slots after its half of the ring (the other half, or the row's 8-element
+        // pad): a valid address whose value is not used.
+        const int i0 = (k & 1) * kTile;
+        if (live) q7_tile(y, c, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
+        else group(k * kTile, xrow[i0]);
         wave_lds_sync();
-        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
+        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane, kRing - 1);
     }
     SA_Q15_STAMP_END();
 }
