@@ -839,6 +839,14 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
             first = false;
         }
     } else {
+#ifdef SA_STAGGER
+        // probe: the first round of workgroups starts in lockstep (every CU loads, then every CU computes); delay
+        // the 2nd..4th workgroup of each CU by SA_STAGGER x 1.8 us each so that their phases interleave at once
+        if (blockIdx.x < 1024) {
+            const int k = (blockIdx.x >> 8) & 3;
+            for (int i = 0; i < k * SA_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+        }
+#endif
         chain_frame<NSEC, UNIT, OUT, WINGEN, false>(in, out, f, -1, true, smem, winb, twT, twB, twC, lanetab, ka);
     }
 }

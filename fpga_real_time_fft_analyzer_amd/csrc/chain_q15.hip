@@ -623,38 +623,85 @@ constexpr int kFftThreads = 256;
 
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 
-// y = sat16((u * w) >> 15), truncation; e == 0 is an exact pass-through (SA-FXFFT-1)
-__device__ __forceinline__ unsigned fx_twiddle(int ur, int ui, unsigned w, bool unity)
+// The four outputs of a butterfly leave the adder tree as 32-bit sums X (re), Y (im) that still want the >> 2 of
+// the spec.  Shift and pack are one instruction per half: v_ashrrev_i32 in its SDWA form writes the low word of
+// its result into the chosen half of the destination (the first write zeroes the other half, the second preserves
+// it); (sum of four int16) >> 2 lies in [-32768, 32767], so taking the low word is exact.  gfx950 wants one
+// instruction between a sub-dword write and a read of the same register (the preserving write reads it): the four
+// first-half writes come first, then the four second-half writes, then one s_nop before the compiler's code.
+//   LO* / HI*: which sum goes to the low / high word of output 0..3.
+#define SA_FX_PACK4(P0, P1, P2, P3, LO0, LO1, LO2, LO3, HI0, HI1, HI2, HI3)                                            \
+    asm("v_ashrrev_i32_sdwa %0, %12, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"        \
+        "v_ashrrev_i32_sdwa %1, %12, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"        \
+        "v_ashrrev_i32_sdwa %2, %12, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"        \
+        "v_ashrrev_i32_sdwa %3, %12, %7 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"        \
+        "v_ashrrev_i32_sdwa %0, %12, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"   \
+        "v_ashrrev_i32_sdwa %1, %12, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"   \
+        "v_ashrrev_i32_sdwa %2, %12, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"  \
+        "v_ashrrev_i32_sdwa %3, %12, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"  \
+        "s_nop 0"                                                                                                      \
+        : "=&v"(P0), "=&v"(P1), "=&v"(P2), "=&v"(P3)                                                                   \
+        : "v"(LO0), "v"(LO1), "v"(LO2), "v"(LO3), "v"(HI0), "v"(HI1), "v"(HI2), "v"(HI3), "v"(2))
+
+// lo(a) lo(b) + hi(a) hi(b), exact in 32 bits.  Written out: the builtin is selected as the accumulating two-operand
+// form v_dot2c_i32_i16, which costs a v_mov of zero into the accumulator per product.
+__device__ __forceinline__ int fx_dot2(unsigned a, unsigned b)
 {
-    // (sum of four int16) >> 2 lies in [-32768, 32767] already: the saturation of the spec cannot trigger on a
-    // pass-through, only after a twiddle product (|u w| >> 15 reaches 65534)
-    if (unity) return sat_pack2(ur, ui);          // in range: the saturation is the identity, the pack is what is wanted
-    const int wr = lo16(w), wi = hi16(w);
-    const int pr = (ur * wr - ui * wi) >> 15;
-    const int pi = (ur * wi + ui * wr) >> 15;
-    return sat_pack2(pr, pi);
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// y = sat16((u * w) >> 15), truncation (SA-FXFFT-1), for u packed as p = (lo = u.im, hi = u.re):
+//   y.im = u.im wr + u.re wi = p . (wr, wi);   y.re = u.re wr - u.im wi = p . (-wi, wr)
+// wi = -32768 has no int16 negation; the table holds it for the exponents 4082..4110 (-32768 sin rounds to -32768
+// that far around pi/2).  Output 2 meets them in every stage (exponent 2 e1), so its real part is always formed
+// from the halves with two 24-bit multiplies; outputs 1 and 3 meet them only in stages 0 and 1 and there only in
+// the butterflies u = 15 (e1 = 4082..4095) and u = 5 (3 e1 = 4083..4110) of a thread, which take the same form
+// (`wide1`, `wide3`: compile-time, the u loops are unrolled).  Everything else takes both words of the table.
+__device__ __forceinline__ unsigned fx_twiddle13(unsigned p, uint2 w)
+{
+    return sat_pack2(fx_dot2(p, w.y) >> 15, fx_dot2(p, w.x) >> 15);
+}
+__device__ __forceinline__ unsigned fx_twiddle2(unsigned p, unsigned w)
+{
+    const int pr = (hi16(p) * lo16(w) - lo16(p) * hi16(w)) >> 15;
+    return sat_pack2(pr, fx_dot2(p, w) >> 15);
 }
 
 // one radix-4 DIF butterfly of SA-FXFFT-1 on packed (re, im) int16 pairs: 32-bit sums, >> 2 (truncation),
 // Q15 twiddles on outputs 1..3 (exact pass-through when the exponent is 0), saturation to int16
-__device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, unsigned w1, unsigned w2,
-                                             unsigned w3, bool unity, unsigned (&o)[4])
+__device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, uint2 w1, unsigned w2,
+                                             uint2 w3, bool unity, unsigned (&o)[4], bool wide1 = false,
+                                             bool wide3 = false)
 {
     const int ar = lo16(a), ai = hi16(a), br = lo16(b), bi = hi16(b);
     const int cr = lo16(c), ci = hi16(c), dr = lo16(d), di = hi16(d);
     const int sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;      // a +/- c
     const int ur = br + dr, ui = bi + di, vr = br - dr, vi = bi - di;      // b +/- d
-    o[0] = sat_pack2((sr + ur) >> 2, (si + ui) >> 2);                      // in range by construction, see fx_twiddle
-    o[1] = fx_twiddle((tr + vi) >> 2, (ti - vr) >> 2, w1, unity);          // a - i b - c + i d
-    o[2] = fx_twiddle((sr - ur) >> 2, (si - ui) >> 2, w2, unity);
-    o[3] = fx_twiddle((tr - vi) >> 2, (ti + vr) >> 2, w3, unity);          // a + i b - c - i d
+    const int x0 = sr + ur, y0 = si + ui;
+    const int x1 = tr + vi, y1 = ti - vr;                                  // a - i b - c + i d
+    const int x2 = sr - ur, y2 = si - ui;
+    const int x3 = tr - vi, y3 = ti + vr;                                  // a + i b - c - i d
+    unsigned p0, p1, p2, p3;
+    if (unity) {
+        // pass-through: the results are in range by construction, the pack is all that is left
+        SA_FX_PACK4(p0, p1, p2, p3, x0, x1, x2, x3, y0, y1, y2, y3);
+        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
+    } else {
+        SA_FX_PACK4(p0, p1, p2, p3, x0, y1, y2, y3, y0, x1, x2, x3);       // outputs 1..3 as (im, re) for the products
+        o[0] = p0;
+        o[1] = wide1 ? fx_twiddle2(p1, w1.x) : fx_twiddle13(p1, w1);
+        o[2] = fx_twiddle2(p2, w2);
+        o[3] = wide3 ? fx_twiddle2(p3, w3.x) : fx_twiddle13(p3, w3);
+    }
 }
 
 template <bool WINDOW>
 __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
                                                                   int16_t *__restrict__ out_iq, int batch,
                                                                   SaQ15Params prm, const int16_t *__restrict__ rom,
-                                                                  const unsigned *__restrict__ tw)
+                                                                  const uint2 *__restrict__ tw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
     unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
@@ -721,7 +768,8 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
                 const int kap = bf & ((1 << sh) - 1);
                 const int e1 = jp << sh;
                 unsigned o[4];
-                fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o);
+                fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 15,
+                             s < 2 && u == 5);
                 const int ob = (jp << (sh + 2)) | kap;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
@@ -735,7 +783,7 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             unsigned o[4];
-            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[u * 256], tw[2 * u * 256], tw[3 * u * 256], u == 0, o);
+            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[u * 256], tw[2 * u * 256].x, tw[3 * u * 256], u == 0, o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
         }
@@ -744,7 +792,7 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
         for (int u = 0; u < 16; ++u) {
             unsigned o[4];
             const int jp = u >> 2;
-            fx_butterfly(w[u], w[u + 16], w[u + 32], w[u + 48], tw[jp * 1024], tw[2 * jp * 1024], tw[3 * jp * 1024],
+            fx_butterfly(w[u], w[u + 16], w[u + 32], w[u + 48], tw[jp * 1024], tw[2 * jp * 1024].x, tw[3 * jp * 1024],
                          jp == 0, o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[16 * jp + 4 * i + (u & 3)] = o[i];
@@ -756,7 +804,7 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             unsigned o[4];
-            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], 0u, 0u, 0u, true, o);
+            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], make_uint2(0u, 0u), 0u, make_uint2(0u, 0u), true, o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(o[i], o32 + t + 256 * (u + 16 * i));   // streaming: written once
         }

@@ -103,7 +103,7 @@ hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_ki
 
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM
-    const uint32_t *tw;        // [16384] packed Q15 twiddles (wr | wi << 16)
+    const uint2 *tw;           // [16384] Q15 twiddles as packed int16 pairs: x = (wr, wi), y = (-wi, wr)
 };
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,

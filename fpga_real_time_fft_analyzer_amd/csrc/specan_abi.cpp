@@ -233,7 +233,7 @@ struct sa_handle {
     float2 *d_twC = nullptr;
     SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
     int16_t *d_rom = nullptr;
-    uint32_t *d_twq = nullptr;
+    uint2 *d_twq = nullptr;          // SA-FXFFT-1 twiddles, {(wr, wi), (-wi, wr)} packed int16 pairs
     int16_t *d_work = nullptr;
     int work_frames = 0;
     // ---- stream-ordered control plane (no device-wide synchronisation anywhere after sa_create)
@@ -500,7 +500,7 @@ int sa_create(int device, sa_handle **out)
     SA_HIPC(hipMalloc(&h->d_lt_default, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
-    SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint32_t) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint2) * SA_NPTS));
 
     // float tables
     {
@@ -561,15 +561,20 @@ int sa_create(int device, sa_handle **out)
     {
         default_rom(h->rom);
         SA_HIPC(hipMemcpy(h->d_rom, h->rom.data(), sizeof(int16_t) * SA_NPTS, hipMemcpyHostToDevice));
-        std::vector<uint32_t> tq(SA_NPTS);
+        std::vector<uint2> tq(SA_NPTS);
         for (int m = 0; m < SA_NPTS; ++m) {   // SA-FXFFT-1 twiddles: clamp16(rint(32768 cos)), clamp16(rint(-32768 sin))
             const double a = 2.0 * M_PI * (double)m / (double)SA_NPTS;
             long wr = std::lrint(32768.0 * std::cos(a)), wi = std::lrint(-32768.0 * std::sin(a));
             wr = wr > 32767 ? 32767 : (wr < -32768 ? -32768 : wr);
             wi = wi > 32767 ? 32767 : (wi < -32768 ? -32768 : wi);
-            tq[m] = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
+            // second word (-wi, wr): the operand of the two-term dot product for the real part.  -wi does not fit
+            // for wi = -32768 (exponents 4082..4110); the kernel never takes the second word of those entries
+            // (fx_butterfly: `wide1`, `wide3`)
+            const long nwi = -wi > 32767 ? 32767 : -wi;
+            tq[m].x = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
+            tq[m].y = ((uint32_t)nwi & 0xFFFFu) | ((uint32_t)wr << 16);
         }
-        SA_HIPC(hipMemcpy(h->d_twq, tq.data(), sizeof(uint32_t) * SA_NPTS, hipMemcpyHostToDevice));
+        SA_HIPC(hipMemcpy(h->d_twq, tq.data(), sizeof(uint2) * SA_NPTS, hipMemcpyHostToDevice));
     }
     SA_HIPC(hipDeviceSynchronize());          // creation only: the blocking copies above are complete
 #undef SA_HIPC
