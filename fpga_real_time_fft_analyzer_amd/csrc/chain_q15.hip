@@ -641,7 +641,7 @@ __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -3
         "v_ashrrev_i32_sdwa %3, %12, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"  \
         "s_nop 0"                                                                                                      \
         : "=&v"(P0), "=&v"(P1), "=&v"(P2), "=&v"(P3)                                                                   \
-        : "v"(LO0), "v"(LO1), "v"(LO2), "v"(LO3), "v"(HI0), "v"(HI1), "v"(HI2), "v"(HI3), "v"(2))
+        : "v"(LO0), "v"(LO1), "v"(LO2), "v"(LO3), "v"(HI0), "v"(HI1), "v"(HI2), "v"(HI3), "s"(2))
 
 // lo(a) lo(b) + hi(a) hi(b), exact in 32 bits.  Written out: the builtin is selected as the accumulating two-operand
 // form v_dot2c_i32_i16, which costs a v_mov of zero into the accumulator per product.
@@ -698,7 +698,7 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
 }
 
 template <bool WINDOW>
-__global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
+__global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel_t256(const int16_t *__restrict__ in,
                                                                   int16_t *__restrict__ out_iq, int batch,
                                                                   SaQ15Params prm, const int16_t *__restrict__ rom,
                                                                   const uint2 *__restrict__ tw)
@@ -811,6 +811,107 @@ __global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel(const int16_t *
     }
 }
 
+// The same transform with 1024 threads per frame: 16 positions per thread (t + 1024 m), stages 0..4 through LDS,
+// stages 5 and 6 in registers.  One more LDS pass than the 256-thread form above, but 50 instead of 124 registers
+// per thread: two workgroups per CU (the frame's 64 KiB of LDS decides that) are then 8 waves per SIMD instead of
+// 2, and the kernel, whose waves otherwise spend a quarter of their life in s_waitcnt behind a barrier with one
+// other wave to cover for them, runs at the rate of its vector instructions.
+constexpr int kFftWide = 1024;
+
+template <bool WINDOW>
+__global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
+                                                               int16_t *__restrict__ out_iq, int batch,
+                                                               SaQ15Params prm, const int16_t *__restrict__ rom,
+                                                               const uint2 *__restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+    unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
+    const int t = threadIdx.x;
+    const int f = blockIdx.x;
+    if (f >= batch) return;
+    // ---- load: 8 samples per 16-byte read, optional window, imag = 0 (new/command_control.vhd:123)
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS);
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(rom);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = t + kFftWide * i;
+        const uint4 xv = x4[u];
+        unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        int s[8];
+        if constexpr (WINDOW) {
+            const uint4 cv = c4[u];
+            const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (prm.win_mode == SA_WIN_RTL_SIGNED) {
+                    s[2 * k] = win_rtl(lo16(xs[k]), lo16(cs[k]));
+                    s[2 * k + 1] = win_rtl(hi16(xs[k]), hi16(cs[k]));
+                } else {
+                    s[2 * k] = win_u16(lo16(xs[k]), lo16(cs[k]));
+                    s[2 * k + 1] = win_u16(hi16(xs[k]), hi16(cs[k]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[2 * k] = lo16(xs[k]);
+                s[2 * k + 1] = hi16(xs[k]);
+            }
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(buf + 8 * u);
+        dst[0] = make_uint4(pack2(s[0], 0), pack2(s[1], 0), pack2(s[2], 0), pack2(s[3], 0));
+        dst[1] = make_uint4(pack2(s[4], 0), pack2(s[5], 0), pack2(s[6], 0), pack2(s[7], 0));
+    }
+    __syncthreads();
+
+    // ---- stages 0..4 (addressing as in the 256-thread form): butterfly bf = t + 1024 u, u = 0..3.
+    // From stage 3 on j' = bf >> 2s is the same for the whole wave: scalar twiddle loads.
+    // Exponents with wi = -32768 (see fx_butterfly): stages 0 and 1, u = 3 for output 1, u = 1 for output 3.
+    unsigned v[16];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int sh = 2 * s;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = buf[t + kFftWide * m];     // m = u + 4 i
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bf = t + kFftWide * u;
+            const int jp = (s >= 3) ? (__builtin_amdgcn_readfirstlane(t >> sh) + (kFftWide >> sh) * u) : (bf >> sh);
+            const int kap = bf & ((1 << sh) - 1);
+            const int e1 = jp << sh;
+            unsigned o[4];
+            fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
+                         s < 2 && u == 1);
+            const int ob = (jp << (sh + 2)) | kap;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = buf[t + kFftWide * m];
+    unsigned w[16];
+    // stage 5 (4^s = 1024): j' = u, kappa = t; outputs land at m' = 4u + i'; exponents are compile-time
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned o[4];
+        fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[u * 1024], tw[2 * u * 1024].x, tw[3 * u * 1024], u == 0, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
+    }
+    // stage 6 (4^s = 4096): no twiddles; outputs at m' = u + 4 i' = natural-order bin t + 1024 m'
+    // frame layout: [16384] x (re, im) int16 = 65536 bytes (imp/sequ2.vhd:153); one dword per lane
+    unsigned *o32 = reinterpret_cast<unsigned *>(out_iq + (size_t)f * SA_NPTS * 2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned o[4];
+        fx_butterfly(w[u], w[u + 4], w[u + 8], w[u + 12], make_uint2(0u, 0u), 0u, make_uint2(0u, 0u), true, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(o[i], o32 + t + kFftWide * (u + 4 * i));   // streaming: written once
+    }
+}
+
 }  // namespace
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
@@ -835,19 +936,13 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream)
 {
     if (batch <= 0) return hipSuccess;
-    const dim3 grid(batch), block(kFftThreads);
+    static const bool t256 = std::getenv("SA_FFT_T256") != nullptr;        // A/B switch for tools/ab_q15.py
+    const dim3 grid(batch), block(t256 ? kFftThreads : kFftWide);
     const int lds = SA_NPTS * 4;
-    hipError_t e;
-    if (apply_window) {
-        auto k = fft_q15_kernel<true>;
-        e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
-    } else {
-        auto k = fft_q15_kernel<false>;
-        e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
-    }
+    auto k = apply_window ? (t256 ? fft_q15_kernel_t256<true> : fft_q15_kernel<true>)
+                          : (t256 ? fft_q15_kernel_t256<false> : fft_q15_kernel<false>);
+    const hipError_t e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
     return hipGetLastError();
 }

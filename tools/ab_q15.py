@@ -16,6 +16,12 @@ ot = torch.empty((B, 16384), dtype=torch.int16, device="cuda")
 oq = torch.empty((B, 16384, 2), dtype=torch.int16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for name in sys.argv[1:]:
+    # "lib.so:VAR=value": the variable is set while this library runs its first calls (launch-time switches are read once)
+    envkey = None
+    if ":" in name:
+        name, kv = name.split(":", 1)
+        envkey, val = kv.split("=", 1)
+        os.environ[envkey] = val
     L = C.CDLL(os.path.join(PKG, name))
     h = C.c_void_p()
     assert L.sa_create(0, C.byref(h)) == 0
@@ -38,6 +44,8 @@ for name in sys.argv[1:]:
                 torch.cuda.synchronize()
                 dt = min(dt, (time.perf_counter() - t0) / 8)
             print(f"{name:28s} mode 0x{mode:02X} {label:8s} {dt*1e6:9.1f} us  {B/dt/1e6:6.2f} M frames/s")
+    if envkey:
+        del os.environ[envkey]
 
 # diagnostic: filter kernel with the caches thrashed / after a heavy kernel in between
 big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda")
