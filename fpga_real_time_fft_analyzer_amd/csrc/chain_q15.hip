@@ -619,7 +619,6 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
 }
 
 // ------------------------------------------------------------------------------------------ FFT
-constexpr int kFftThreads = 256;
 
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 
@@ -657,7 +656,7 @@ __device__ __forceinline__ int fx_dot2(unsigned a, unsigned b)
 // wi = -32768 has no int16 negation; the table holds it for the exponents 4082..4110 (-32768 sin rounds to -32768
 // that far around pi/2).  Output 2 meets them in every stage (exponent 2 e1), so its real part is always formed
 // from the halves with two 24-bit multiplies; outputs 1 and 3 meet them only in stages 0 and 1 and there only in
-// the butterflies u = 15 (e1 = 4082..4095) and u = 5 (3 e1 = 4083..4110) of a thread, which take the same form
+// the butterflies u = 3 (e1 = 4082..4095) and u = 1 (3 e1 = 4083..4110) of a thread, which take the same form
 // (`wide1`, `wide3`: compile-time, the u loops are unrolled).  Everything else takes both words of the table.
 __device__ __forceinline__ unsigned fx_twiddle13(unsigned p, uint2 w)
 {
@@ -697,125 +696,15 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
     }
 }
 
-template <bool WINDOW>
-__global__ __launch_bounds__(kFftThreads, 2) void fft_q15_kernel_t256(const int16_t *__restrict__ in,
-                                                                  int16_t *__restrict__ out_iq, int batch,
-                                                                  SaQ15Params prm, const int16_t *__restrict__ rom,
-                                                                  const uint2 *__restrict__ tw)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
-    unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
-    const int t = threadIdx.x;
-
-    {
-        // one frame per workgroup (a frame loop lets the compiler hoist loop-invariant addresses: spills)
-        const int f = blockIdx.x;
-        if (f >= batch) return;
-        // ---- load: 8 samples per 16-byte read, optional window, imag = 0 (new/command_control.vhd:123)
-        const uint4 *x4 = reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS);
-        const uint4 *c4 = reinterpret_cast<const uint4 *>(rom);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int u = t + 256 * i;
-            const uint4 xv = x4[u];
-            unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            int s[8];
-            if constexpr (WINDOW) {
-                const uint4 cv = c4[u];
-                const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (prm.win_mode == SA_WIN_RTL_SIGNED) {
-                        s[2 * k] = win_rtl(lo16(xs[k]), lo16(cs[k]));
-                        s[2 * k + 1] = win_rtl(hi16(xs[k]), hi16(cs[k]));
-                    } else {
-                        s[2 * k] = win_u16(lo16(xs[k]), lo16(cs[k]));
-                        s[2 * k + 1] = win_u16(hi16(xs[k]), hi16(cs[k]));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s[2 * k] = lo16(xs[k]);
-                    s[2 * k + 1] = hi16(xs[k]);
-                }
-            }
-            uint4 *dst = reinterpret_cast<uint4 *>(buf + 8 * u);
-            dst[0] = make_uint4(pack2(s[0], 0), pack2(s[1], 0), pack2(s[2], 0), pack2(s[3], 0));
-            dst[1] = make_uint4(pack2(s[4], 0), pack2(s[5], 0), pack2(s[6], 0), pack2(s[7], 0));
-        }
-        __syncthreads();
-
-        // ---- 7 radix-4 DIF stages, Stockham addressing:
-        //   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
-        //   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
-        //   output i' at (j' << (2s+2)) | (i' << 2s) | kappa; twiddle exponent i' * j' * 4^s.
-        // Thread t owns the 64 positions t + 256 m.  Stages 0..3 scatter their outputs to other threads
-        // (one LDS pass each); from stage 4 on (4^s >= 256) every output stays with its thread, so
-        // stages 4, 5, 6 run in registers and the result is stored straight from them.
-        unsigned v[64];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int sh = 2 * s;
-#pragma unroll
-            for (int m = 0; m < 64; ++m) v[m] = buf[t + 256 * m];      // m = u + 16 i
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int bf = t + 256 * u;
-                // stage 3: j' = (t >> 6) + 4u is the same for the whole wave -> scalar twiddle loads
-                const int jp = (s == 3) ? (__builtin_amdgcn_readfirstlane(t >> 6) + 4 * u) : (bf >> sh);
-                const int kap = bf & ((1 << sh) - 1);
-                const int e1 = jp << sh;
-                unsigned o[4];
-                fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 15,
-                             s < 2 && u == 5);
-                const int ob = (jp << (sh + 2)) | kap;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int m = 0; m < 64; ++m) v[m] = buf[t + 256 * m];
-        unsigned w[64];
-        // stage 4 (4^s = 256): j' = u, kappa = t; outputs land at m' = 4u + i'; exponents are compile-time
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            unsigned o[4];
-            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], tw[u * 256], tw[2 * u * 256].x, tw[3 * u * 256], u == 0, o);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
-        }
-        // stage 5 (4^s = 1024): j' = u >> 2, kappa = t + 256 (u & 3); outputs at m' = 16 (u>>2) + 4 i' + (u&3)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            unsigned o[4];
-            const int jp = u >> 2;
-            fx_butterfly(w[u], w[u + 16], w[u + 32], w[u + 48], tw[jp * 1024], tw[2 * jp * 1024].x, tw[3 * jp * 1024],
-                         jp == 0, o);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[16 * jp + 4 * i + (u & 3)] = o[i];
-        }
-        // stage 6 (4^s = 4096): no twiddles; outputs at m' = u + 16 i' = natural-order bin t + 256 m'
-        // frame layout: [16384] x (re, im) int16 = 65536 bytes (imp/sequ2.vhd:153); one dword per lane,
-        // 256 contiguous bytes per wave instruction
-        unsigned *o32 = reinterpret_cast<unsigned *>(out_iq + (size_t)f * SA_NPTS * 2);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            unsigned o[4];
-            fx_butterfly(v[u], v[u + 16], v[u + 32], v[u + 48], make_uint2(0u, 0u), 0u, make_uint2(0u, 0u), true, o);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(o[i], o32 + t + 256 * (u + 16 * i));   // streaming: written once
-        }
-    }
-}
-
-// The same transform with 1024 threads per frame: 16 positions per thread (t + 1024 m), stages 0..4 through LDS,
-// stages 5 and 6 in registers.  One more LDS pass than the 256-thread form above, but 50 instead of 124 registers
-// per thread: two workgroups per CU (the frame's 64 KiB of LDS decides that) are then 8 waves per SIMD instead of
-// 2, and the kernel, whose waves otherwise spend a quarter of their life in s_waitcnt behind a barrier with one
-// other wave to cover for them, runs at the rate of its vector instructions.
+// SA-FXFFT-1 with 1024 threads per frame: 16 positions per thread (t + 1024 m), stages 0..4 through LDS, stages 5
+// and 6 in registers.  (Round 1 and most of round 2 ran 256 threads x 64 positions, stages 4..6 in registers: one
+// LDS pass fewer, but 120 registers per thread.  The frame's 64 KiB of LDS allow two workgroups per CU either way:
+// that was 2 waves per SIMD, the waves spent a quarter of their life in s_waitcnt behind a barrier with one other
+// wave to cover for them; this is 8 waves per SIMD at 52 registers, 192 -> 155-172 us.)
+//   7 radix-4 DIF stages, Stockham addressing:
+//   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
+//   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
+//   output i' at (j' << (2s+2)) | (i' << 2s) | kappa; twiddle exponent i' * j' * 4^s.
 constexpr int kFftWide = 1024;
 
 template <bool WINDOW>
@@ -864,7 +753,7 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
     }
     __syncthreads();
 
-    // ---- stages 0..4 (addressing as in the 256-thread form): butterfly bf = t + 1024 u, u = 0..3.
+    // ---- stages 0..4: butterfly bf = t + 1024 u, u = 0..3; every output goes to another thread (one LDS pass each).
     // From stage 3 on j' = bf >> 2s is the same for the whole wave: scalar twiddle loads.
     // Exponents with wi = -32768 (see fx_butterfly): stages 0 and 1, u = 3 for output 1, u = 1 for output 3.
     unsigned v[16];
@@ -936,11 +825,9 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream)
 {
     if (batch <= 0) return hipSuccess;
-    static const bool t256 = std::getenv("SA_FFT_T256") != nullptr;        // A/B switch for tools/ab_q15.py
-    const dim3 grid(batch), block(t256 ? kFftThreads : kFftWide);
+    const dim3 grid(batch), block(kFftWide);
     const int lds = SA_NPTS * 4;
-    auto k = apply_window ? (t256 ? fft_q15_kernel_t256<true> : fft_q15_kernel<true>)
-                          : (t256 ? fft_q15_kernel_t256<false> : fft_q15_kernel<false>);
+    auto k = apply_window ? fft_q15_kernel<true> : fft_q15_kernel<false>;
     const hipError_t e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
