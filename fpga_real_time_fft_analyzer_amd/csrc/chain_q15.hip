@@ -650,6 +650,13 @@ __device__ __forceinline__ int fx_dot2(unsigned a, unsigned b)
     asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// the same with a wave-uniform second operand taken straight from its scalar register (no v_mov per product)
+__device__ __forceinline__ int fx_dot2_s(unsigned a, unsigned b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
 
 // y = sat16((u * w) >> 15), truncation (SA-FXFFT-1), for u packed as p = (lo = u.im, hi = u.re):
 //   y.im = u.im wr + u.re wi = p . (wr, wi);   y.re = u.re wr - u.im wi = p . (-wi, wr)
@@ -658,18 +665,23 @@ __device__ __forceinline__ int fx_dot2(unsigned a, unsigned b)
 // from the halves with two 24-bit multiplies; outputs 1 and 3 meet them only in stages 0 and 1 and there only in
 // the butterflies u = 3 (e1 = 4082..4095) and u = 1 (3 e1 = 4083..4110) of a thread, which take the same form
 // (`wide1`, `wide3`: compile-time, the u loops are unrolled).  Everything else takes both words of the table.
+template <bool UNIFORM>
 __device__ __forceinline__ unsigned fx_twiddle13(unsigned p, uint2 w)
 {
-    return sat_pack2(fx_dot2(p, w.y) >> 15, fx_dot2(p, w.x) >> 15);
+    if constexpr (UNIFORM) return sat_pack2(fx_dot2_s(p, w.y) >> 15, fx_dot2_s(p, w.x) >> 15);
+    else return sat_pack2(fx_dot2(p, w.y) >> 15, fx_dot2(p, w.x) >> 15);
 }
+template <bool UNIFORM>
 __device__ __forceinline__ unsigned fx_twiddle2(unsigned p, unsigned w)
 {
     const int pr = (hi16(p) * lo16(w) - lo16(p) * hi16(w)) >> 15;
-    return sat_pack2(pr, fx_dot2(p, w) >> 15);
+    return sat_pack2(pr, (UNIFORM ? fx_dot2_s(p, w) : fx_dot2(p, w)) >> 15);
 }
 
 // one radix-4 DIF butterfly of SA-FXFFT-1 on packed (re, im) int16 pairs: 32-bit sums, >> 2 (truncation),
 // Q15 twiddles on outputs 1..3 (exact pass-through when the exponent is 0), saturation to int16
+// UNIFORM: the twiddles are the same for the whole wave (scalar loads, or compile-time exponents)
+template <bool UNIFORM = false>
 __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, uint2 w1, unsigned w2,
                                              uint2 w3, bool unity, unsigned (&o)[4], bool wide1 = false,
                                              bool wide3 = false)
@@ -690,9 +702,9 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
     } else {
         SA_FX_PACK4(p0, p1, p2, p3, x0, y1, y2, y3, y0, x1, x2, x3);       // outputs 1..3 as (im, re) for the products
         o[0] = p0;
-        o[1] = wide1 ? fx_twiddle2(p1, w1.x) : fx_twiddle13(p1, w1);
-        o[2] = fx_twiddle2(p2, w2);
-        o[3] = wide3 ? fx_twiddle2(p3, w3.x) : fx_twiddle13(p3, w3);
+        o[1] = wide1 ? fx_twiddle2<UNIFORM>(p1, w1.x) : fx_twiddle13<UNIFORM>(p1, w1);
+        o[2] = fx_twiddle2<UNIFORM>(p2, w2);
+        o[3] = wide3 ? fx_twiddle2<UNIFORM>(p3, w3.x) : fx_twiddle13<UNIFORM>(p3, w3);
     }
 }
 
@@ -770,8 +782,11 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
             const int kap = bf & ((1 << sh) - 1);
             const int e1 = jp << sh;
             unsigned o[4];
-            fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
-                         s < 2 && u == 1);
+            if (s >= 3)
+                fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o);
+            else
+                fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
+                             s < 2 && u == 1);
             const int ob = (jp << (sh + 2)) | kap;
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         unsigned o[4];
-        fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[u * 1024], tw[2 * u * 1024].x, tw[3 * u * 1024], u == 0, o);
+        fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[u * 1024], tw[2 * u * 1024].x, tw[3 * u * 1024], u == 0, o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
     }
