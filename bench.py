@@ -51,12 +51,36 @@ def _cpu_slice(args):
     return time.perf_counter() - t0
 
 
+def usable_cores() -> tuple:
+    """(cores this process may actually use, note): the affinity mask capped by the cgroup CPU quota -- a GPU box
+    shows all of the host's cores in the mask while the job owns a share of them."""
+    import math
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())    # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        return aff, f"{aff} cores in the affinity mask, no cgroup CPU quota"
+    n = max(1, min(aff, int(math.ceil(quota))))
+    return n, f"{aff} cores in the affinity mask, cgroup CPU quota {quota:g}"
+
+
 def cpu_baseline(sos: np.ndarray) -> dict:
     """scipy/numpy chain on a bounded sample, single thread and all cores.
     Runs before anything touches the GPU (it forks a worker pool)."""
     from multiprocessing import get_context
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0))
+    cores, cores_note = usable_cores()
     hann = orc.hann_f64().astype(np.float32)
     x1 = synth_host(256, seed=1)
     orc.cpu_baseline_chain(x1[:8], sos, hann)                # warm-up
@@ -78,7 +102,7 @@ def cpu_baseline(sos: np.ndarray) -> dict:
             "single_thread_frames_per_s": round(fps_single, 1),
             "sample": f"np.abs(np.fft.rfft(scipy.signal.sosfilt(sos, x*hann))) float32 in / float64 inside; "
                       f"single thread on 256 frames, {cores}-process pool on {nslices * 64} frames "
-                      f"(64-frame slices), same synthetic distribution as the GPU run"}
+                      f"(64-frame slices), same synthetic distribution as the GPU run; {cores_note}"}
 
 
 def _free_port() -> int:
