@@ -708,6 +708,47 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
     }
 }
 
+// The first stage's butterfly: the inputs are real (imag = 0, new/command_control.vhd:123), which leaves 7 of the 16
+// additions and 6 of the 8 shift-and-insert instructions: with s = a + c, t = a - c, u = b + d, v = b - d
+//   out0 = (s + u, 0)    out1 = (t, -v)    out2 = (s - u, 0)    out3 = (t, v)        (each >> 2)
+// and output 2's twiddle product is two multiplies (its imaginary input is 0).  Same results as fx_butterfly on
+// (a, 0) .. (d, 0) by construction; a, b, c, d are sign-extended 16-bit samples.
+__device__ __forceinline__ void fx_butterfly_real(int a, int b, int c, int d, uint2 w1, unsigned w2, uint2 w3, bool unity,
+                                                  unsigned (&o)[4], bool wide1, bool wide3)
+{
+    const int sr = a + c, tr = a - c, ur = b + d, vr = b - d, nv = d - b;
+    const int x0 = sr + ur, x2 = sr - ur;
+    unsigned p0, p1, p2, p3;
+    if (unity) {
+        // (re, im) pairs as stored: out0 = (x0, 0), out1 = (t, -v), out2 = (x2, 0), out3 = (t, v)
+        asm("v_ashrrev_i32_sdwa %0, %9, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %1, %9, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %2, %9, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %3, %9, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %1, %9, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %3, %9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "s_nop 0"
+            : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+            : "v"(x0), "v"(tr), "v"(x2), "v"(nv), "v"(vr), "s"(2));
+        o[0] = p0; o[1] = p1; o[2] = p2; o[3] = p3;
+    } else {
+        // outputs 1 and 3 as (im, re) for the products, output 2's real input as a plain number
+        asm("v_ashrrev_i32_sdwa %0, %7, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %1, %7, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %2, %7, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %1, %7, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_ashrrev_i32_sdwa %2, %7, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "s_nop 0"
+            : "=&v"(p0), "=&v"(p1), "=&v"(p3)
+            : "v"(x0), "v"(nv), "v"(vr), "v"(tr), "s"(2));
+        const int u2 = x2 >> 2;
+        o[0] = p0;
+        o[1] = wide1 ? fx_twiddle2<false>(p1, w1.x) : fx_twiddle13<false>(p1, w1);
+        o[2] = sat_pack2((u2 * lo16(w2)) >> 15, (u2 * hi16(w2)) >> 15);
+        o[3] = wide3 ? fx_twiddle2<false>(p3, w3.x) : fx_twiddle13<false>(p3, w3);
+    }
+}
+
 // SA-FXFFT-1 with 1024 threads per frame: 16 positions per thread (t + 1024 m), stages 0..4 through LDS, stages 5
 // and 6 in registers.  (Round 1 and most of round 2 ran 256 threads x 64 positions, stages 4..6 in registers: one
 // LDS pass fewer, but 120 registers per thread.  The frame's 64 KiB of LDS allow two workgroups per CU either way:
@@ -730,47 +771,38 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
     const int t = threadIdx.x;
     const int f = blockIdx.x;
     if (f >= batch) return;
-    // ---- load: 8 samples per 16-byte read, optional window, imag = 0 (new/command_control.vhd:123)
-    const uint4 *x4 = reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS);
-    const uint4 *c4 = reinterpret_cast<const uint4 *>(rom);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = t + kFftWide * i;
-        const uint4 xv = x4[u];
-        unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        int s[8];
-        if constexpr (WINDOW) {
-            const uint4 cv = c4[u];
-            const unsigned cs[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (prm.win_mode == SA_WIN_RTL_SIGNED) {
-                    s[2 * k] = win_rtl(lo16(xs[k]), lo16(cs[k]));
-                    s[2 * k + 1] = win_rtl(hi16(xs[k]), hi16(cs[k]));
-                } else {
-                    s[2 * k] = win_u16(lo16(xs[k]), lo16(cs[k]));
-                    s[2 * k + 1] = win_u16(hi16(xs[k]), hi16(cs[k]));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s[2 * k] = lo16(xs[k]);
-                s[2 * k + 1] = hi16(xs[k]);
-            }
-        }
-        uint4 *dst = reinterpret_cast<uint4 *>(buf + 8 * u);
-        dst[0] = make_uint4(pack2(s[0], 0), pack2(s[1], 0), pack2(s[2], 0), pack2(s[3], 0));
-        dst[1] = make_uint4(pack2(s[4], 0), pack2(s[5], 0), pack2(s[6], 0), pack2(s[7], 0));
-    }
-    __syncthreads();
-
-    // ---- stages 0..4: butterfly bf = t + 1024 u, u = 0..3; every output goes to another thread (one LDS pass each).
-    // From stage 3 on j' = bf >> 2s is the same for the whole wave: scalar twiddle loads.
+    // ---- stage 0 straight from global memory: the thread's 16 positions t + 1024 m as 2-byte loads (128 contiguous
+    // bytes per wave instruction), optional window, imag = 0 (new/command_control.vhd:123).  No staging pass
+    // through LDS, no barrier in front of the first butterflies; outputs 4 bf + i' are one 16-byte LDS write.
     // Exponents with wi = -32768 (see fx_butterfly): stages 0 and 1, u = 3 for output 1, u = 1 for output 3.
+    {
+        const int16_t *xf = in + (size_t)f * SA_NPTS + t;
+        int x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = xf[kFftWide * m];
+        if constexpr (WINDOW) {
+            int c[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) c[m] = rom[t + kFftWide * m];
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                x[m] = (prm.win_mode == SA_WIN_RTL_SIGNED) ? win_rtl(x[m], c[m]) : win_u16(x[m], c[m]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bf = t + kFftWide * u;                   // j' = bf, kappa = 0, e1 = bf
+            unsigned o[4];
+            fx_butterfly_real(x[u], x[u + 4], x[u + 8], x[u + 12], tw[bf], tw[2 * bf].x, tw[3 * bf], bf == 0, o, u == 3, u == 1);
+            *reinterpret_cast<uint4 *>(buf + 4 * bf) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+    }
+
+    // ---- stages 1..4: butterfly bf = t + 1024 u, u = 0..3; every output goes to another thread (one LDS pass each).
+    // From stage 3 on j' = bf >> 2s is the same for the whole wave: scalar twiddle loads.
     unsigned v[16];
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
+    for (int s = 1; s < 5; ++s) {
         const int sh = 2 * s;
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = buf[t + kFftWide * m];     // m = u + 4 i
