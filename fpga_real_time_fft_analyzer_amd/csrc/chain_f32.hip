@@ -217,6 +217,63 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Probe (-DSA_STAGE_HYBRID): chunk A through the LDS-DMA as in stage_in_chunks, chunk B as eight 16-byte loads of the
+// thread's own samples, both requested at once: ONE memory round trip in front of the IIR instead of two (the
+// 32 KiB image holds half a frame).  Costs the address processing of eight divergent loads (64 lines each).
+template <bool WINGEN>
+__device__ __forceinline__ void stage_in_hybrid(const float *__restrict__ xin, const float4 *__restrict__ wint,
+                                                const SaIirLaneTab *__restrict__ lt, unsigned char *smem, int t,
+                                                v2f (&d)[32])
+{
+    const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
+    const int lane = t & 63, wave = t >> 6;
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float g0 = 0.f;
+    if constexpr (WINGEN) {
+        pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);
+        g0 = lt->wg0;
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(xin + 64 * t + 32);
+    float4 qb[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) qb[g] = src[g];
+    dma_chunk_half(xin, 0, smem, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int sw = (t >> 1) & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g == 4) __builtin_amdgcn_sched_barrier(0);
+            const float4 q = h == 0 ? lds4[t * 8 + (g ^ sw)] : qb[g];
+            float4 w;
+            if constexpr (WINGEN) {
+                float wv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    wv[e] = __builtin_fmaf(Q, lt->wcs[4 * g + e][1], __builtin_fmaf(P, lt->wcs[4 * g + e][0], g0));
+                w = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            } else {
+                w = wint[(8 * h + g) * 256 + t];
+            }
+            if (h == 0) {
+                d[4 * g + 0].x = mul_to(q.x, w.x);
+                d[4 * g + 1].x = mul_to(q.y, w.y);
+                d[4 * g + 2].x = mul_to(q.z, w.z);
+                d[4 * g + 3].x = mul_to(q.w, w.w);
+            } else {
+                d[4 * g + 0].y = mul_to(q.x, w.x);
+                d[4 * g + 1].y = mul_to(q.y, w.y);
+                d[4 * g + 2].y = mul_to(q.z, w.z);
+                d[4 * g + 3].y = mul_to(q.w, w.w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage-in for the IIR without LDS: thread t loads ITS OWN 64 consecutive samples (256 bytes) with sixteen
 // 16-byte loads.  The lanes of one load instruction are 256 bytes apart, but each 128-byte line is completed by
 // eight instructions of the same wave, and the memory system delivers this pattern at the rate of a coalesced
@@ -578,6 +635,8 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         v2f d[32];
 #if defined(SA_STAGE_DIRECT)
         stage_in_direct<WINGEN>(xin, lanetab, t, d);
+#elif defined(SA_STAGE_HYBRID)
+        stage_in_hybrid<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
 #else
         stage_in_chunks<WINGEN, PERSIST>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d,
                                          !first_frame);
