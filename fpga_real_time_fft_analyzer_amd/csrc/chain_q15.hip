@@ -44,22 +44,20 @@ extern "C" int sa_debug_set_q15_stamps(void *p)
 namespace {
 
 // ------------------------------------------------------------------------------------------ window
-// new/hann8192.vhd:36-39: out = resize16(product(31..15) + product(14))
+// new/hann8192.vhd:36-39: out = resize16(product(31..15) + product(14)).
+// product(31..15) + product(14) = floor((p + 2^14) / 2^15); resize16 of the 17-bit sum keeps its sign bit (16) and its
+// low 15 bits, which differs from plain truncation only for +32768 (x = c = -32768), mapped to 0.
 __device__ __forceinline__ int win_rtl(int x, int c)
 {
-    const int p = x * c;
-    const int r = (p >> 15) + ((p >> 14) & 1);
-    const unsigned r17 = (unsigned)r & 0x1FFFFu;
-    const unsigned o = (r17 & 0x7FFFu) | (((r17 >> 16) & 1u) << 15);
-    return (int)(short)o;
+    const int r = (x * c + 16384) >> 15;
+    return (int)(short)((r & 0x7FFF) | ((r >> 1) & 0x8000));
 }
 
-// SURVEY quirk Q2 alternative: ROM + 32768 as unsigned Q16 Hann, round half up
+// SURVEY quirk Q2 alternative: ROM + 32768 as unsigned Q16 Hann, round half up.  |x (c + 32768) + 32768| < 2^31 for
+// 16-bit x and c (largest 32767 * 65535 + 32768): 32-bit arithmetic is exact.
 __device__ __forceinline__ int win_u16(int x, int c)
 {
-    const int w = c + 32768;
-    const long long p = (long long)x * w + 32768;
-    return (int)(short)(p >> 16);
+    return (int)(short)((x * (c + 32768) + 32768) >> 16);
 }
 
 __device__ __forceinline__ unsigned pack2(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }

@@ -135,6 +135,22 @@ def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
         ch.set_window_mode_q15(wm)
         ref = oracle.chain_q15(x, rom, wm, 0xB1, None, None)
         assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), ref)
+    # the corners of the window arithmetic: x = c = -32768 (the 17-bit sum +32768 that resize16 maps to 0,
+    # new/hann8192.vhd:36-39), full-scale products of either sign, in the FFT-side and the filter-side window
+    xf = rng.integers(-32768, 32768, size=(3, N)).astype(np.int16)
+    rom[::97] = -32768
+    xf[:, ::97] = -32768
+    rom[5::97] = 32767
+    xf[0, 5::97] = 32767
+    xf[1, 5::97] = -32768
+    ch.set_window_q15(rom)
+    for wm in (0, 1):
+        ch.set_window_mode_q15(wm)
+        for cmd in (0xB1, 0x00):
+            ch.set_filter_mode(cmd)
+            ref = oracle.chain_q15(xf, rom, wm, cmd, None, None)
+            assert np.array_equal(ch.process_q15(_dev(torch_mod, xf)).cpu().numpy(), ref), (wm, cmd)
+    ch.set_filter_mode(0xB1)
     ch.set_window_q15(None)
     ch.set_window_mode_q15(0)
     assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), oracle.chain_q15(x))
