@@ -416,10 +416,10 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
 // depending on a 4-byte s_nop in front of them or between them), so the loop is pinned: 64-byte aligned, nothing of
 // the compiler's inside it, `s_nop 0` where SA_Q7_NOPS (bit p = after instruction p of the block, order
 // H G B C A I D F E) says.  Per group: select the refill into t, request the next refill (16-bit LDS read, used
-// one group later: lgkmcnt(1) = everything but the store behind it), eight blocks, pack lane 8's eight outputs and
-// store them under an exec mask (restored five instructions before the next DPP read, as the hardware asks).
+// one group later: lgkmcnt(2) = everything but the two stores behind it), eight blocks, lane 8's eight outputs
+// stored as dwords under an exec mask (restored five instructions before the next DPP read, as the hardware asks).
 #ifndef SA_Q7_NOPS
-#define SA_Q7_NOPS 0x080
+#define SA_Q7_NOPS 0x000      // timed on the real kernel for every change of the loop's layout (tools/ab_q15.py)
 #endif
 #if SA_Q7_NOPS & 0x001
 #define SA_N0 "s_nop 0\n\t"
@@ -467,27 +467,28 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
 #define SA_N8
 #endif
 #define SA_Q7_TBLOCK(Y, H1)                                                                                            \
-    "v_add_u32_sdwa %[" Y "], %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t" SA_N0 \
+    "v_add_u32_sdwa " Y ", %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t" SA_N0   \
     "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N1  \
-    "v_mul_i32_i24_dpp %[p2], %[" H1 "], %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N2                        \
-    "v_mul_i32_i24_dpp %[p0], %[" Y "], %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N3                         \
-    "v_mad_i32_i24 %[p4], %[" Y "], %[nA1], %[k]\n\t" SA_N4                                                            \
+    "v_mul_i32_i24_dpp %[p2], " H1 ", %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N2                           \
+    "v_mul_i32_i24_dpp %[p0], " Y ", %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N3                            \
+    "v_mad_i32_i24 %[p4], " Y ", %[nA1], %[k]\n\t" SA_N4                                                               \
     "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" SA_N5   \
-    "v_mul_i32_i24_dpp %[p1], %[" Y "], %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N6                         \
+    "v_mul_i32_i24_dpp %[p1], " Y ", %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N6                            \
     "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N7  \
-    "v_mad_i32_i24 %[p3], %[" Y "], %[nA0], %[k]\n\t" SA_N8
-#define SA_Q7_TGROUP(RD_OFF, WR_OFF)                                                                                   \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                                                         \
+    "v_mad_i32_i24 %[p3], " Y ", %[nA0], %[k]\n\t" SA_N8
+// The lane's last eight outputs live in v52..v59 inside the loop (named registers: the two 16-byte stores of lane 8
+// need them consecutive, and an asm operand cannot be addressed by sub-register); they are stored as sign-extended
+// dwords, the saturating pack to int16 happens once per sample in the flush, where all 64 lanes have work, instead
+// of four times per group here, where lane 8 of each row is the only one with a use for it.
+#define SA_Q7_TGROUP(RD_OFF, WR_OFF0, WR_OFF1)                                                                         \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                         \
     "v_cndmask_b32_e64 %[t], %[t], %[xin], %[inm]\n\t"                                                                 \
     "ds_read_u16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
-    SA_Q7_TBLOCK("y0", "y7") SA_Q7_TBLOCK("y1", "y0") SA_Q7_TBLOCK("y2", "y1") SA_Q7_TBLOCK("y3", "y2")                \
-    SA_Q7_TBLOCK("y4", "y3") SA_Q7_TBLOCK("y5", "y4") SA_Q7_TBLOCK("y6", "y5") SA_Q7_TBLOCK("y7", "y6")                \
-    "v_cvt_pk_i16_i32 v60, %[y0], %[y1]\n\t"                                                                           \
-    "v_cvt_pk_i16_i32 v61, %[y2], %[y3]\n\t"                                                                           \
-    "v_cvt_pk_i16_i32 v62, %[y4], %[y5]\n\t"                                                                           \
-    "v_cvt_pk_i16_i32 v63, %[y6], %[y7]\n\t"                                                                           \
+    SA_Q7_TBLOCK("v52", "v59") SA_Q7_TBLOCK("v53", "v52") SA_Q7_TBLOCK("v54", "v53") SA_Q7_TBLOCK("v55", "v54")        \
+    SA_Q7_TBLOCK("v56", "v55") SA_Q7_TBLOCK("v57", "v56") SA_Q7_TBLOCK("v58", "v57") SA_Q7_TBLOCK("v59", "v58")        \
     "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
-    "ds_write_b128 %[ra], v[60:63] offset:" WR_OFF "\n\t"                                                              \
+    "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF0 "\n\t"                                                             \
+    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"                                                             \
     "s_mov_b64 exec, %[sv]\n\t"
 
 // xa: LDS byte address of the lane's refill slot of the tile's first group; ra: of the ring slot of its outputs
@@ -497,23 +498,46 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
     int xin, cnt = kTile / 32;
     unsigned long long saved;
     asm volatile(
+        "v_mov_b32 v52, %[y0]\n\tv_mov_b32 v53, %[y1]\n\tv_mov_b32 v54, %[y2]\n\tv_mov_b32 v55, %[y3]\n\t"
+        "v_mov_b32 v56, %[y4]\n\tv_mov_b32 v57, %[y5]\n\tv_mov_b32 v58, %[y6]\n\tv_mov_b32 v59, %[y7]\n\t"
         "ds_read_u16 %[xin], %[xa]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"                      // first group: nothing in flight, lgkmcnt(1) passes
+        "s_waitcnt lgkmcnt(0)\n\t"                      // first group: nothing in flight, lgkmcnt(2) passes
         ".p2align 6\n"
         "1:\n\t"
-        SA_Q7_TGROUP("16", "0") SA_Q7_TGROUP("32", "16") SA_Q7_TGROUP("48", "32") SA_Q7_TGROUP("64", "48")
+        SA_Q7_TGROUP("16", "0", "16") SA_Q7_TGROUP("32", "32", "48") SA_Q7_TGROUP("48", "64", "80") SA_Q7_TGROUP("64", "96", "112")
         "v_add_u32 %[xa], 64, %[xa]\n\t"
-        "v_add_u32 %[ra], 64, %[ra]\n\t"
+        "v_add_u32 %[ra], 0x80, %[ra]\n\t"
         "s_add_i32 %[cnt], %[cnt], -1\n\t"
         "s_cmp_lg_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mov_b32 %[y0], v52\n\tv_mov_b32 %[y1], v53\n\tv_mov_b32 %[y2], v54\n\tv_mov_b32 %[y3], v55\n\t"
+        "v_mov_b32 %[y4], v56\n\tv_mov_b32 %[y5], v57\n\tv_mov_b32 %[y6], v58\n\tv_mov_b32 %[y7], v59"
         : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]),
           [y7] "+v"(y[7]), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p1] "+v"(c.p1), [p2] "+v"(c.p2), [p3] "+v"(c.p3), [p4] "+v"(c.p4),
           [t] "+v"(c.t), [u] "+v"(c.u), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt), [sv] "=&s"(saved)
         : [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask),
           [outm] "s"(out_mask)
-        : "memory", "scc", "v60", "v61", "v62", "v63");
+        : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+}
+
+// flush one tile of the dword ring: 8 samples per lane, packed to int16 with saturation (exact: the values are
+// sign-extended 16-bit numbers) and stored as 16 bytes
+__device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const int (*src)[kRingPitch], int src_col, int f0,
+                                              int batch, int n0, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < kFramesPerWave / 2; ++i) {
+        const int row = 2 * i + (lane >> 5);
+        const int col = (lane & 31) * 8;
+        const int f = f0 + row;
+        const int sc = (src_col + col) & (kRing - 1);       // 8-sample chunks: the ring wraps between chunks only
+        const int4 a = *reinterpret_cast<const int4 *>(&src[row][sc]);
+        const int4 b = *reinterpret_cast<const int4 *>(&src[row][sc + 4]);
+        if (f < batch)
+            *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) =
+                make_uint4(sat_pack2(a.x, a.y), sat_pack2(a.z, a.w), sat_pack2(b.x, b.y), sat_pack2(b.z, b.w));
+    }
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -526,11 +550,11 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
                                                                    int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
 {
     __shared__ __attribute__((aligned(16))) int16_t tin_all[kV2Waves][kFramesPerWave][kInPitch];
-    __shared__ __attribute__((aligned(16))) int16_t ring_all[kV2Waves][kFramesPerWave][kRingPitch];
+    __shared__ __attribute__((aligned(16))) int ring_all[kV2Waves][kFramesPerWave][kRingPitch];     // outputs as dwords
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
-    int16_t (*ring)[kRingPitch] = ring_all[wave];
+    int (*ring)[kRingPitch] = ring_all[wave];
     const int fr = lane >> 4;           // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
     const uint16_t *xrow = reinterpret_cast<const uint16_t *>(&tin[fr][0]) + (is_in ? kin : 0);
     const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const uint16_t *)xrow;
-    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)(&ring[fr][0]);
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)(&ring[fr][0]);
 
     int y[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the lane's last eight outputs
     Q7Carry c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -566,9 +590,11 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         c.t = is_in ? xin : c.t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) q7_block(y[e], c, y[(e + 7) & 7], cB2, cB1, cB0, nA0, nA1, k127);
-        q7_u4 v;
-        v.x = sat_pack2(y[0], y[1]); v.y = sat_pack2(y[2], y[3]); v.z = sat_pack2(y[4], y[5]); v.w = sat_pack2(y[6], y[7]);
-        lds_store16_masked(ring_addr + 2 * (T0 & (kRing - 1)), v, out_mask);
+        q7_u4 va, vb;
+        va.x = y[0]; va.y = y[1]; va.z = y[2]; va.w = y[3];
+        vb.x = y[4]; vb.y = y[5]; vb.z = y[6]; vb.w = y[7];
+        lds_store16_masked(ring_addr + 4 * (T0 & (kRing - 1)), va, out_mask);
+        lds_store16_masked(ring_addr + 4 * (T0 & (kRing - 1)) + 16, vb, out_mask);
     };
 
     Q15TileRegs pre;
@@ -608,10 +634,10 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         // group of a tile requests the slots after its half of the ring (the other half, or the row's 8-element
         // pad): a valid address whose value is not used.
         const int i0 = (k & 1) * kTile;
-        if (live) q7_tile(y, c, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
+        if (live) q7_tile(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
         else group(k * kTile, xrow[i0]);
         wave_lds_sync();
-        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane, kRing - 1);
+        if (k >= 1) q7_flush_tile(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane);
     }
     SA_Q15_STAMP_END();
 }
