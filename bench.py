@@ -319,6 +319,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Rank 0 prints ONE line on stdout.  Libraries underneath do not know that (gloo announces its connections on
+    # stdout): file descriptor 1 points at stderr for the duration of the run and is restored for the JSON line only.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if world > 1:
         import datetime
         dist.init_process_group(backend="gloo", rank=rank, world_size=world,
@@ -408,7 +414,10 @@ def main():
             line["cpu_baseline"] = cpu
         if extras:
             line["extras"] = extras
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     wl.close()
     if world > 1:
         dist.barrier()

@@ -112,6 +112,8 @@ def test_bench_under_torchrun_env_and_mismatch():
     outs = [p.communicate(timeout=300)[0] for p in ps]
     assert all(p.returncode == 0 for p in ps)
     assert '"n_gpus": 2' in outs[0] and "{" not in outs[1]              # only rank 0 prints the JSON line
+    # ... and nothing else reaches stdout (gloo announces its connections there unless the bench keeps it away)
+    assert len(outs[0].strip().splitlines()) == 1 and outs[1].strip() == ""
 
 
 def test_bench_launcher_fails_when_a_rank_fails():
