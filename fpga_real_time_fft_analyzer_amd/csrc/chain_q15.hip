@@ -685,10 +685,10 @@ __device__ __forceinline__ int fx_dot2_s(unsigned a, unsigned b)
 // y = sat16((u * w) >> 15), truncation (SA-FXFFT-1), for u packed as p = (lo = u.im, hi = u.re):
 //   y.im = u.im wr + u.re wi = p . (wr, wi);   y.re = u.re wr - u.im wi = p . (-wi, wr)
 // wi = -32768 has no int16 negation; the table holds it for the exponents 4082..4110 (-32768 sin rounds to -32768
-// that far around pi/2).  Output 2 meets them in every stage (exponent 2 e1), so its real part is always formed
-// from the halves with two 24-bit multiplies; outputs 1 and 3 meet them only in stages 0 and 1 and there only in
-// the butterflies u = 3 (e1 = 4082..4095) and u = 1 (3 e1 = 4083..4110) of a thread, which take the same form
-// (`wide1`, `wide3`: compile-time, the u loops are unrolled).  Everything else takes both words of the table.
+// that far around pi/2).  Which butterflies of a thread can meet them is known at compile time (the u loops are
+// unrolled): output 1 in stages 0 and 1 at u = 3 (e1 = 4082..4095), output 3 there at u = 1 (3 e1 = 4083..4110),
+// output 2 at u = 1 or 2 in stages 0 and 1 and at u = 2 from stage 2 on (2 e1 = 4082..4110).  Those form the real
+// part from the halves with two 24-bit multiplies (`wide1..3`); everything else takes both words of the table.
 template <bool UNIFORM>
 __device__ __forceinline__ unsigned fx_twiddle13(unsigned p, uint2 w)
 {
@@ -706,9 +706,8 @@ __device__ __forceinline__ unsigned fx_twiddle2(unsigned p, unsigned w)
 // Q15 twiddles on outputs 1..3 (exact pass-through when the exponent is 0), saturation to int16
 // UNIFORM: the twiddles are the same for the whole wave (scalar loads, or compile-time exponents)
 template <bool UNIFORM = false>
-__device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, uint2 w1, unsigned w2,
-                                             uint2 w3, bool unity, unsigned (&o)[4], bool wide1 = false,
-                                             bool wide3 = false)
+__device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c, unsigned d, uint2 w1, uint2 w2,
+                                             uint2 w3, bool unity, unsigned (&o)[4], bool wide1, bool wide2, bool wide3)
 {
     const int ar = lo16(a), ai = hi16(a), br = lo16(b), bi = hi16(b);
     const int cr = lo16(c), ci = hi16(c), dr = lo16(d), di = hi16(d);
@@ -727,7 +726,7 @@ __device__ __forceinline__ void fx_butterfly(unsigned a, unsigned b, unsigned c,
         SA_FX_PACK4(p0, p1, p2, p3, x0, y1, y2, y3, y0, x1, x2, x3);       // outputs 1..3 as (im, re) for the products
         o[0] = p0;
         o[1] = wide1 ? fx_twiddle2<UNIFORM>(p1, w1.x) : fx_twiddle13<UNIFORM>(p1, w1);
-        o[2] = fx_twiddle2<UNIFORM>(p2, w2);
+        o[2] = wide2 ? fx_twiddle2<UNIFORM>(p2, w2.x) : fx_twiddle13<UNIFORM>(p2, w2);
         o[3] = wide3 ? fx_twiddle2<UNIFORM>(p3, w3.x) : fx_twiddle13<UNIFORM>(p3, w3);
     }
 }
@@ -838,11 +837,14 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
             const int kap = bf & ((1 << sh) - 1);
             const int e1 = jp << sh;
             unsigned o[4];
+            // exponents with wi = -32768 (see fx_butterfly): output 1 in stage 1 at u = 3, output 3 at u = 1,
+            // output 2 at u = 1 or 2 in stage 1 and at u = 2 from stage 2 on
             if (s >= 3)
-                fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o);
+                fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o, false, u == 2,
+                                   false);
             else
-                fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1].x, tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
-                             s < 2 && u == 1);
+                fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
+                             s < 2 ? (u == 1 || u == 2) : (u == 2), s < 2 && u == 1);
             const int ob = (jp << (sh + 2)) | kap;
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
@@ -856,7 +858,8 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         unsigned o[4];
-        fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[u * 1024], tw[2 * u * 1024].x, tw[3 * u * 1024], u == 0, o);
+        fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[u * 1024], tw[2 * u * 1024], tw[3 * u * 1024], u == 0, o, false,
+                           u == 2, false);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[4 * u + i] = o[i];
     }
@@ -866,7 +869,8 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         unsigned o[4];
-        fx_butterfly(w[u], w[u + 4], w[u + 8], w[u + 12], make_uint2(0u, 0u), 0u, make_uint2(0u, 0u), true, o);
+        fx_butterfly(w[u], w[u + 4], w[u + 8], w[u + 12], make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), true, o, false,
+                     false, false);
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(o[i], o32 + t + kFftWide * (u + 4 * i));   // streaming: written once
     }
