@@ -569,8 +569,15 @@ int sa_create(int device, sa_handle **out)
             wi = wi > 32767 ? 32767 : (wi < -32768 ? -32768 : wi);
             // second word (-wi, wr): the operand of the two-term dot product for the real part.  -wi does not fit
             // for wi = -32768 (exponents 4082..4110); the kernel never takes the second word of those entries
-            // (fx_butterfly: `wide1`, `wide3`)
+            // (fx_butterfly: `wide1`, `wide2`, `wide3`)
             const long nwi = -wi > 32767 ? 32767 : -wi;
+            // the kernel's compile-time choice of the butterflies that avoid the second word rests on this range
+            // (margins: 32768 sin = 32767.528 at 4082 and 4110, 32767.458 at 4081 and 4111; the threshold is .5)
+            if (wi == -32768 && (m < 4082 || m > 4110)) {
+                g_create_error = "sa_create: twiddle table: wi = -32768 outside exponents 4082..4110";
+                sa_destroy(h);
+                return SA_ESTATE;
+            }
             tq[m].x = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
             tq[m].y = ((uint32_t)nwi & 0xFFFFu) | ((uint32_t)wr << 16);
         }
