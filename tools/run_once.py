@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tiny driver for profilers: run the fused float chain a few times.  usage: run_once.py MODE B ITERS"""
+"""Tiny driver for profilers: run the fused float chain a few times.  usage: run_once.py MODE B ITERS [OUT_KIND]"""
 import os
 import sys
 
@@ -31,7 +31,8 @@ gen = torch.Generator(device="cuda").manual_seed(1)
 n = torch.arange(16384, device="cuda", dtype=torch.float32)
 fb = torch.rand(B, 1, generator=gen, device="cuda") * 0.44 + 0.01
 x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, 16384, generator=gen, device="cuda")).contiguous()
-out = torch.empty_like(x)
+kind = sys.argv[4] if len(sys.argv) > 4 else "mag_full"
+out = ch.process_f32(x, out_kind=kind)
 for _ in range(iters):
-    ch.process_f32(x, out=out)
+    ch.process_f32(x, out=out, out_kind=kind)
 torch.cuda.synchronize()
