@@ -10,6 +10,14 @@ timing barrier / max-reduce, done over gloo on the host.
 
 Prints ONE JSON line on rank 0 with the driver's keys plus ``roofline`` and ``cpu_baseline``.
 
+Headline mode: overlapped launches (``sa_set_overlap``, include/specan.h) -- ``--overlap D`` (default 2) keeps D
+launches of the handle in flight, so the tail of one batch runs under the head of the next (frames are
+independent: new/filter_iir12_cust.vhd:48-63 resets the state per frame).  The line says so
+(``launches_in_flight``), its ``roofline`` is computed from the WALL time per step of the timed region (kernels
+overlap, so per-kernel event durations no longer add up), and the strictly stream-ordered figures -- wall and
+per-kernel HIP events, the number a ``rocprofv3 --kernel-trace`` of ``--overlap 1`` reproduces -- are kept beside
+it under ``ordered``.  ``--overlap 1`` makes the ordered mode the headline.
+
 Two ways to get N ranks (one process per GPU, BASELINE.json configs[4]):
   * under ``torch.distributed.run`` (WORLD_SIZE in the environment): this process IS one rank;
   * plain ``python bench.py --gpus N``: this process becomes a launcher that starts N fresh rank
@@ -77,19 +85,22 @@ def usable_cores() -> tuple:
 
 def cpu_baseline(sos: np.ndarray) -> dict:
     """scipy/numpy chain on a bounded sample, single thread and all cores.
-    Runs before anything touches the GPU (it forks a worker pool)."""
+    Runs before anything touches the GPU (it forks a worker pool).  SA_BENCH_CPU_SECONDS bounds the all-core
+    sample (default 10 s of aggregate CPU work; the CPU tests of the launcher use a fraction of a second)."""
     from multiprocessing import get_context
     from oracle import oracle as orc
     cores, cores_note = usable_cores()
+    budget = float(os.environ.get("SA_BENCH_CPU_SECONDS", "10"))
     hann = orc.hann_f64().astype(np.float32)
-    x1 = synth_host(256, seed=1)
+    n_single = 256 if budget >= 5 else 16
+    x1 = synth_host(n_single, seed=1)
     orc.cpu_baseline_chain(x1[:8], sos, hann)                # warm-up
     t0 = time.perf_counter()
     orc.cpu_baseline_chain(x1, sos, hann)
     t_single = time.perf_counter() - t0
     fps_single = x1.shape[0] / t_single
-    # all cores: about 10 s of aggregate CPU work, one 64-frame slice per task
-    per_worker = max(64, int(fps_single * 10.0 / 64) * 64 // max(cores, 1) // 64 * 64)
+    # all cores: about `budget` seconds of aggregate CPU work, one 64-frame slice per task
+    per_worker = max(64, int(fps_single * budget / 64) * 64 // max(cores, 1) // 64 * 64)
     nslices = cores * max(1, per_worker // 64)
     xs = synth_host(64, seed=2)
     with get_context("fork").Pool(cores) as pool:
@@ -101,7 +112,7 @@ def cpu_baseline(sos: np.ndarray) -> dict:
     return {"value": round(fps_all, 1), "unit": "frames/s", "cores": cores, "kind": "port",
             "single_thread_frames_per_s": round(fps_single, 1),
             "sample": f"np.abs(np.fft.rfft(scipy.signal.sosfilt(sos, x*hann))) float32 in / float64 inside; "
-                      f"single thread on 256 frames, {cores}-process pool on {nslices * 64} frames "
+                      f"single thread on {n_single} frames, {cores}-process pool on {nslices * 64} frames "
                       f"(64-frame slices), same synthetic distribution as the GPU run; {cores_note}"}
 
 
@@ -116,11 +127,17 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     """Launcher mode: start ``n`` rank processes of this script (one per GPU), relay rank 0's line.
     Nothing here imports torch or touches a GPU.  Returns the exit code for the launcher."""
     import subprocess
+    # the CPU baseline of the same run, on the same host cores, BEFORE the ranks start (they would compete for the
+    # cores): handed to rank 0 through the environment, which puts it into its line
+    cpu_json = ""
+    if "--no-cpu-baseline" not in argv:
+        sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]
+        cpu_json = json.dumps(cpu_baseline(sos))
     port = _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SA_BENCH_CPU_JSON=cpu_json if r == 0 else "")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, rc, deadline = "", 0, time.time() + float(os.environ.get("SA_BENCH_LAUNCH_TIMEOUT", "1500"))
@@ -184,6 +201,9 @@ class StubDevice:
     def sync(self):
         pass
 
+    def set_overlap(self, depth):
+        pass
+
     def kernel_ms(self, steps):
         return [2.0 * (1 + self.rank)] * steps
 
@@ -226,7 +246,16 @@ class GpuWorkload:
         self.step_no += 1
         self.ch.process_f32(self.xs[i], out=self.outs[i])
 
+    def set_overlap(self, depth):
+        """Launches of the handle kept in flight (include/specan.h, sa_set_overlap).  The rotating buffer pairs
+        satisfy the mode's contract: a pair is reused R steps later, R > depth."""
+        if depth > 1 and self.R <= depth:
+            raise SystemExit(f"bench.py: --overlap {depth} needs more than {depth} buffer pairs (--buffers)")
+        self.ch.set_overlap(depth)
+
     def sync(self):
+        if self.ch.overlap > 1:
+            self.ch.flush()                           # the current stream waits for the internal streams
         self.torch.cuda.synchronize(self.dev)
 
     def kernel_ms(self, steps):
@@ -255,6 +284,7 @@ class GpuWorkload:
                 fn()
             self.sync()
             return (time.perf_counter() - t) / k
+        ch.set_overlap(1)
         ch.set_filter_mode(0xB1)
         x256 = self.xs[0][:256].contiguous()
         o256 = self.outs[0][:256]
@@ -276,6 +306,14 @@ class GpuWorkload:
                 ch.set_filter_mode(cmd)
                 dt = time_it(qstep, 5)
                 out[name + tag] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+            if R > 2:        # config 4 with two launches in flight: the FFT of batch k under the filter of batch k+1
+                ch.set_overlap(2)
+                ch.reserve(B)
+                ch.set_filter_mode(0x00)
+                dt = time_it(qstep, 6)
+                out["config4_q15_default_iir" + tag + "_overlap2"] = {"frames_per_s": B / dt,
+                                                                     "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+                ch.set_overlap(1)
             del xqs, oqs
         ch.set_filter_mode(0xA1)
         return out
@@ -293,11 +331,16 @@ def main():
     ap.add_argument("--buffers", type=int, default=4,
                     help="input/output buffer pairs used round-robin (one pair of 256 MiB + 256 MiB would stay in "
                          "the 256 MB Infinity Cache from step to step: the figure would be a cache figure, not HBM)")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="launches of the handle kept in flight in the timed region (sa_set_overlap; 1 = strictly "
+                         "stream-ordered, which is also measured and reported under 'ordered')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time the bypass (config 2) and Q15 (config 4) paths")
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if not 1 <= a.overlap <= 4:
+        ap.error("--overlap must be 1..4")
 
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:                               # launcher mode: no GPU call has happened in this process
@@ -312,9 +355,15 @@ def main():
     stub = os.environ.get("SA_BENCH_STUB") == "1"
     sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]    # 12th-order Butterworth, wn = 0.2
 
+    # CPU baseline beside every line, N > 1 included (north_star: "next to the scipy/numpy CPU baseline timed on
+    # the same host cores in the same run"): from the launcher when it started the ranks, else measured here by
+    # rank 0 before anything initialises the GPU (it forks; the other ranks wait in the rendezvous meanwhile)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not stub:
-        cpu = cpu_baseline(sos)                      # before any GPU initialisation (forks)
+    if rank == 0 and not a.no_cpu_baseline:
+        if os.environ.get("SA_BENCH_CPU_JSON"):
+            cpu = json.loads(os.environ["SA_BENCH_CPU_JSON"])
+        else:
+            cpu = cpu_baseline(sos)
 
     import torch
     import torch.distributed as dist
@@ -341,30 +390,44 @@ def main():
         if world > 1:
             dist.barrier()
 
+    from bench_shard import aggregate_fps, gather_floats
+
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(a.warmup):
+            wl.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.step()
+        wl.sync()
+        t1 = time.perf_counter()
+        res = aggregate_fps(B, a.steps, t1 - t0, world)                 # MAX over ranks (gloo, host side)
+        if world > 1:
+            dist.barrier()
+        return res
+
     # Untimed pre-warm: the chip leaves its idle power state only after ~100 ms of sustained load (the
     # same launches measured 8-10 % slower in the first milliseconds).  Then the W contract warm-up steps.
+    wl.set_overlap(a.overlap)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < (0.0 if stub else 0.25):
         for _ in range(10):
             wl.step()
         wl.sync()
-    for _ in range(a.warmup):
-        wl.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step()
-    wl.sync()
-    t1 = time.perf_counter()
-    from bench_shard import aggregate_fps
-    fps_total, elapsed = aggregate_fps(B, a.steps, t1 - t0, world)     # MAX over ranks (gloo, host side)
-    if world > 1:
-        dist.barrier()
+    fps_total, elapsed = timed_region()                                  # the headline
 
-    # per-launch kernel time with HIP events on the launch stream, same number of steps
+    # strictly stream-ordered mode: wall (same contract) and per-launch kernel time with HIP events on the launch
+    # stream, same number of steps -- what rocprofv3 --kernel-trace shows for `--overlap 1`
+    wl.set_overlap(1)
+    if a.overlap > 1:
+        fps_ord, elapsed_ord = timed_region()
+    else:
+        fps_ord, elapsed_ord = fps_total, elapsed
     k_ms = sorted(wl.kernel_ms(a.steps))
     k_avg_ms = float(np.mean(k_ms))
     k_med_ms = float(k_ms[len(k_ms) // 2])
+    per_rank_kernel_ms = gather_floats(k_avg_ms, world)                  # launch skew between GPUs, if any
 
     extras = wl.extras(a.steps) if (a.extras and rank == 0 and not stub) else {}
 
@@ -374,7 +437,7 @@ def main():
         # read inside the timed process, so this is a constant quoted from that profile -- `traffic_source`
         # says which -- and null when the profile was taken at another batch size.
         traffic, traffic_src = None, None
-        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for name in ("r3_pmc_traffic.json",):        # regenerated with the round's kernel (tools/pmc_profile.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pj = json.load(fh)
@@ -383,7 +446,10 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 continue
-        achieved = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
+        ms_step = elapsed / a.steps * 1e3
+        achieved_ord = B * BYTES_PER_FRAME_F32 / (k_avg_ms * 1e-3) / 1e9
+        # overlap mode: kernels run beside each other, so bytes / wall time per step (per GPU) is the achieved rate
+        achieved = B * BYTES_PER_FRAME_F32 / (ms_step * 1e-3) / 1e9 if a.overlap > 1 else achieved_ord
         line = {
             "metric": "16K-pt frames/sec (window+IIR+FFT), batch=4096",
             "value": round(fps_total, 1),
@@ -392,6 +458,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "launches_in_flight": a.overlap,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -401,15 +468,25 @@ def main():
                                    f"wn=0.2) + 16K FFT + magnitude, all 16384 bins written (BASELINE.json configs[2]"
                                    f"{'; x' + str(world) + ' GPUs = configs[4]' if world > 1 else ''})",
                        "frames_per_gpu": B, "sharding": "batch, independent per-GPU streams, no collective",
-                       "buffer_pairs": R, "seeds": [10 + r for r in range(world)]},
+                       "buffer_pairs": R, "seeds": [10 + r for r in range(world)],
+                       "launch_mode": (f"sa_set_overlap({a.overlap}): results of a call visible after the next "
+                                       f"{a.overlap - 1} call(s) or sa_flush" if a.overlap > 1 else "stream-ordered")},
+            "per_rank_kernel_ms": [round(v, 4) for v in per_rank_kernel_ms],
         }
         if not stub:
             line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "traffic_source": traffic_src,
+                                "basis": (f"wall ms_per_step of the timed region, {a.overlap} launches in flight "
+                                          f"(per-kernel durations overlap)" if a.overlap > 1
+                                          else "per-launch HIP events on the launch stream"),
                                 "kernel": wl.kernel_name, "kernel_ms_avg": round(k_avg_ms, 4),
                                 "kernel_ms_median": round(k_med_ms, 4),
                                 "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32}
+            line["ordered"] = {"value": round(fps_ord, 1), "ms_per_step": round(elapsed_ord / a.steps * 1e3, 4),
+                               "kernel_ms_avg": round(k_avg_ms, 4), "achieved": round(achieved_ord, 1),
+                               "frac": round(achieved_ord / HBM_PEAK_GBS, 4),
+                               "basis": "strictly stream-ordered launches; per-launch HIP events on the launch stream"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if extras:

@@ -20,3 +20,14 @@ def aggregate_fps(frames_per_rank: int, steps: int, elapsed: float, world: int) 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t[0])
     return frames_per_rank * world * steps / tmax, tmax
+
+
+def gather_floats(value: float, world: int) -> list[float]:
+    """One float per rank, in rank order, on every rank (gloo all_gather on the host; timing data only)."""
+    if world == 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, torch.tensor([value], dtype=torch.float64))
+    return [float(t[0]) for t in out]

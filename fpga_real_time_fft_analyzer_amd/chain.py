@@ -197,6 +197,22 @@ class SpectrumChain:
     def reserve(self, max_batch: int):
         self._check(self._lib.sa_reserve(self._h, int(max_batch)))
 
+    def set_overlap(self, depth: int):
+        """Opt-in overlapped launches (include/specan.h, sa_set_overlap): with depth d > 1 the results of a
+        process call are visible on the current stream after d-1 further calls or after :meth:`flush`, and the
+        call's input and output tensors belong to the library until then.  1 = strictly stream-ordered."""
+        self._check(self._lib.sa_set_overlap(self._h, int(depth)))
+
+    @property
+    def overlap(self) -> int:
+        v = C.c_int()
+        self._check(self._lib.sa_get_overlap(self._h, C.byref(v)))
+        return v.value
+
+    def flush(self):
+        """Make the current stream wait for every outstanding overlapped call (no host wait)."""
+        self._check(self._lib.sa_flush(self._h, self._stream()))
+
     def iir_plan(self) -> np.ndarray:
         n = self._lib.sa_debug_iir_plan_f32(self._h, None, 0)
         out = np.zeros(n, np.float32)

@@ -21,8 +21,6 @@
 // The factor 1/2 of the split step is folded into the window table (exact in binary fp).
 #include "sa_common.hpp"
 #include "fft_regs.hpp"
-#include <atomic>
-#include <cstdlib>
 #include "../../include/specan.h"
 
 using safft::cf;
@@ -140,16 +138,19 @@ __device__ __forceinline__ void dma_chunk_half(const float *__restrict__ xin, in
     __builtin_amdgcn_s_setprio(0);
 }
 
-// PREISSUED (persistent workgroups): round 0's DMA was requested earlier -- by the kernel prologue, or by the
-// previous frame just before its last group of output stores (`behind_stores` of them, issued after the DMA).
-template <bool WINGEN, bool PREISSUED>
+template <bool WINGEN>
 __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, const float4 *__restrict__ wint,
                                                 const SaIirLaneTab *__restrict__ lt, unsigned char *smem, int t,
-                                                v2f (&d)[32], bool behind_stores = false)
+                                                v2f (&d)[32])
 {
     const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
-    const int lane = t & 63, wave = PREISSUED ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
-    // WINGEN: the window a0 - a1 cos(theta n) evaluated in place (see stage_in_direct): W = G0 + P_h c_j + Q_h s_j
+    const int lane = t & 63, wave = t >> 6;
+    // WINGEN: the window is a0 - a1 cos(2 pi n / (N-1)) (Hann, Hamming; what scripts/hann_coeff.py:3-4 generates) and is
+    // evaluated in place by the angle-addition formula: with n = 64 t + 32 h + j,
+    //   W[n] = G0 + P_h c_j + Q_h s_j,   c_j = cos(theta j), s_j = sin(theta j) wave-uniform (scalar loads),
+    //   (P_h, Q_h) = S a1 (-cos, sin)(theta (64 t + 32 h)) per thread and chunk, G0 = S a0, S = 0.5 * cascade gain.
+    // The 64 KiB per-frame read of the window table (L2 -> L1, 16 more loads per thread) is gone.  !WINGEN (any other
+    // window): the transposed table.
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
     float g0 = 0.f;
     if constexpr (WINGEN) {
@@ -163,22 +164,8 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         // DMA (vmcnt) and, before overwriting the rows with round 1, for its own reads of round 0 (lgkmcnt).
         // Three barriers fewer per frame; a wave delayed on its SIMD no longer holds the other three here.
         if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(PREISSUED && h == 0)) {
-            int lane_d = lane;
-            // persistent form: derive this round's eight source addresses here, not ahead of round 0's window
-            // arithmetic where they would be computed early, kept across it and spilled
-            if constexpr (PREISSUED) asm volatile("" : "+v"(lane_d));
-            dma_chunk_half(xin, h, smem, lane_d, wave);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (behind_stores) {
-            // The DMA is the OLDEST vector-memory traffic of this wave; the four 16-byte output stores of the
-            // previous frame's last group were issued after it.  vmcnt(4) = "all but the 4 youngest are done" =
-            // the DMA has landed while those stores may still be draining.  (The barrier: the previous frame's
-            // readers of the image, other waves included, were done before the DMA was issued.)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        dma_chunk_half(xin, h, smem, lane, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // nothing of the window arithmetic below may be scheduled above the wait (register-only instructions do
         // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
         __builtin_amdgcn_sched_barrier(0);
@@ -212,120 +199,6 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
                 d[4 * g + 2].y = mul_to(q.z, w.z);
                 d[4 * g + 3].y = mul_to(q.w, w.w);
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Probe (-DSA_STAGE_HYBRID): chunk A through the LDS-DMA as in stage_in_chunks, chunk B as eight 16-byte loads of the
-// thread's own samples, both requested at once: ONE memory round trip in front of the IIR instead of two (the
-// 32 KiB image holds half a frame).  Costs the address processing of eight divergent loads (64 lines each).
-template <bool WINGEN>
-__device__ __forceinline__ void stage_in_hybrid(const float *__restrict__ xin, const float4 *__restrict__ wint,
-                                                const SaIirLaneTab *__restrict__ lt, unsigned char *smem, int t,
-                                                v2f (&d)[32])
-{
-    const float4 *lds4 = reinterpret_cast<const float4 *>(smem);
-    const int lane = t & 63, wave = t >> 6;
-    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-    float g0 = 0.f;
-    if constexpr (WINGEN) {
-        pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);
-        g0 = lt->wg0;
-    }
-    const float4 *src = reinterpret_cast<const float4 *>(xin + 64 * t + 32);
-    float4 qb[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) qb[g] = src[g];
-    dma_chunk_half(xin, 0, smem, lane, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int sw = (t >> 1) & 7;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g == 4) __builtin_amdgcn_sched_barrier(0);
-            const float4 q = h == 0 ? lds4[t * 8 + (g ^ sw)] : qb[g];
-            float4 w;
-            if constexpr (WINGEN) {
-                float wv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    wv[e] = __builtin_fmaf(Q, lt->wcs[4 * g + e][1], __builtin_fmaf(P, lt->wcs[4 * g + e][0], g0));
-                w = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            } else {
-                w = wint[(8 * h + g) * 256 + t];
-            }
-            if (h == 0) {
-                d[4 * g + 0].x = mul_to(q.x, w.x);
-                d[4 * g + 1].x = mul_to(q.y, w.y);
-                d[4 * g + 2].x = mul_to(q.z, w.z);
-                d[4 * g + 3].x = mul_to(q.w, w.w);
-            } else {
-                d[4 * g + 0].y = mul_to(q.x, w.x);
-                d[4 * g + 1].y = mul_to(q.y, w.y);
-                d[4 * g + 2].y = mul_to(q.z, w.z);
-                d[4 * g + 3].y = mul_to(q.w, w.w);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Stage-in for the IIR without LDS: thread t loads ITS OWN 64 consecutive samples (256 bytes) with sixteen
-// 16-byte loads.  The lanes of one load instruction are 256 bytes apart, but each 128-byte line is completed by
-// eight instructions of the same wave, and the memory system delivers this pattern at the rate of a coalesced
-// stream (profiles/r2_memory_skeleton.txt: 5.66 TB/s against 5.5-5.8 TB/s for the LDS-DMA form).  No DMA, no
-// transposition through LDS, no barrier, and all sixteen loads are in flight at once.
-//
-// Window.  WINGEN: the window is a0 - a1 cos(2 pi n / (N-1)) (Hann, Hamming; what scripts/hann_coeff.py:3-4
-// generates) and is evaluated in place by the angle-addition formula: with n = 64 t + 32 h + j,
-//   W[n] = G0 + P_h c_j + Q_h s_j,   c_j = cos(theta j), s_j = sin(theta j) wave-uniform (scalar loads),
-//   (P_h, Q_h) = S a1 (-cos, sin)(theta (64 t + 32 h)) per thread and chunk, G0 = S a0, S = 0.5 * cascade gain;
-// two packed FMAs give (W of chunk A, W of chunk B) for one j.  The 64 KiB per-frame read of the window table
-// (L2 -> L1, 16 more loads per thread) is gone.  !WINGEN (any other window): the transposed table as before.
-// Thread t ends with d[j] = (x[64t + j], x[64t + 32 + j]) * window.
-template <bool WINGEN>
-__device__ __forceinline__ void stage_in_direct(const float *__restrict__ xin, const SaIirLaneTab *__restrict__ lt,
-                                                int t, v2f (&d)[32])
-{
-    const float4 *src = reinterpret_cast<const float4 *>(xin + 64 * t);
-    float4 qa[8], qb[8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        qa[g] = src[g];
-        qb[g] = src[8 + g];
-    }
-    if constexpr (WINGEN) {
-        const float4 pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);      // P_A, Q_A, P_B, Q_B
-        const v2f P = {pq.x, pq.z}, Q = {pq.y, pq.w};
-        const float g0s = lt->wg0;
-        const v2f G0 = {g0s, g0s};
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float xa[4] = {qa[g].x, qa[g].y, qa[g].z, qa[g].w}, xb[4] = {qb[g].x, qb[g].y, qb[g].z, qb[g].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 4 * g + e;
-                const v2f cs = {lt->wcs[j][0], lt->wcs[j][1]};                       // wave-uniform: SGPR pair
-                v2f w;
-                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(w) : "v"(P), "s"(cs), "v"(G0));
-                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(w) : "v"(Q), "s"(cs));
-                d[j].x = mul_to(xa[e], w.x);
-                d[j].y = mul_to(xb[e], w.y);
-            }
-        }
-    } else {
-        const float4 *wint = reinterpret_cast<const float4 *>(lt->win_t);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 wa = wint[g * 256 + t], wb = wint[(8 + g) * 256 + t];
-            d[4 * g + 0] = v2f{mul_to(qa[g].x, wa.x), mul_to(qb[g].x, wb.x)};
-            d[4 * g + 1] = v2f{mul_to(qa[g].y, wa.y), mul_to(qb[g].y, wb.y)};
-            d[4 * g + 2] = v2f{mul_to(qa[g].z, wa.z), mul_to(qb[g].z, wb.z)};
-            d[4 * g + 3] = v2f{mul_to(qa[g].w, wa.w), mul_to(qb[g].w, wb.w)};
         }
     }
 }
@@ -598,12 +471,10 @@ __device__ __forceinline__ int zpos_low(int q) { return zrow_pos(q, q >> 9); }
 __device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w >> 9)) & 7); }
 
 // ---------------------------------------------------------------------------------------------
-// One frame: window -> IIR -> FFT -> split -> store.  PERSIST: the workgroup loops over frames; round 0 of this
-// frame's stage-in was requested by the previous frame (or by the kernel prologue), and this frame requests the
-// next one's right after its last LDS read, ahead of its last group of split arithmetic and output stores.
-template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool PERSIST, typename PlanT>
+// One frame: window -> IIR -> FFT -> split -> store.
+template <int NSEC, bool UNIT, int OUT, bool WINGEN, typename PlanT>
 __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *__restrict__ out, const int f,
-                                            const int f_next, const bool first_frame, unsigned char *smem,
+                                            unsigned char *smem,
                                             const float4 *__restrict__ winb, const float4 *__restrict__ twT,
                                             const float4 *__restrict__ twB, const float2 *__restrict__ twC,
                                             const SaIirLaneTab *__restrict__ lanetab, const PlanT &ka)
@@ -612,12 +483,9 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     float2 *scr = reinterpret_cast<float2 *>(smem + kScrOff);
     cf *side = reinterpret_cast<cf *>(smem + kSideOff);
 
-    int t = threadIdx.x;
-    // persistent form: an opaque copy of the thread index per frame, or every per-thread address of the body
-    // is hoisted out of the frame loop and spilled
-    if constexpr (PERSIST) asm volatile("" : "+v"(t));
+    const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = PERSIST ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
+    const int wave = t >> 6;
     const int lo = lane & 15;          // b in pass B, c in pass C
     const int kq = lane >> 4;
     const float *xin = in + (size_t)f * SA_NPTS;
@@ -633,14 +501,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 
     if constexpr (IIR) {
         v2f d[32];
-#if defined(SA_STAGE_DIRECT)
-        stage_in_direct<WINGEN>(xin, lanetab, t, d);
-#elif defined(SA_STAGE_HYBRID)
-        stage_in_hybrid<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
-#else
-        stage_in_chunks<WINGEN, PERSIST>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d,
-                                         !first_frame);
-#endif
+        stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
         SA_STAMP(1);
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
         SA_STAMP(2);
@@ -825,19 +686,6 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
                 zm[4] = side[0];
             }
             if (r == 1 && q0 == 0) zm[0] = side[0];
-            if constexpr (PERSIST && OUT == SA_OUT_MAG_FULL) {
-                if (r == 1 && jj == 1) {
-                    // the frame's last LDS read is done in every wave after this barrier: the image is free, and
-                    // the next frame's first half is requested ahead of this group's arithmetic and 4 stores
-                    lds_barrier();
-                    // an opaque copy of the lane index: without it the eight per-lane source offsets of the DMA are
-                    // shared with the stage-in's (common subexpressions), kept alive across the whole frame and spilled
-                    int lane_p = lane;
-                    asm volatile("" : "+v"(lane_p));
-                    if (f_next >= 0) dma_chunk_half(in + (size_t)f_next * SA_NPTS, 0, smem, lane_p, wave);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
             cf R[5], I[5];
 #pragma unroll
             for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], R[e], I[e]);
@@ -859,7 +707,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 #endif
 }
 
-template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool PERSIST>
+template <int NSEC, bool UNIT, int OUT, bool WINGEN>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
@@ -872,42 +720,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int f = blockIdx.x;
     if (f >= batch) return;
-    if constexpr (PERSIST) {
-        // grid = the workgroups the chip holds at once (4 per CU); workgroup b takes frames b, b + grid, ...
-        static_assert(NSEC > 0 && OUT == SA_OUT_MAG_FULL, "the persistent form is built for the headline kernels");
-        const int step = gridDim.x;
-        dma_chunk_half(in + (size_t)f * SA_NPTS, 0, smem, threadIdx.x & 63, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-        bool first = true;
-        for (;;) {
-            // Everything the body reads from the kernel arguments (2.9 KiB of plan constants, the table pointers)
-            // is loop-invariant: left visible, the compiler hoists hundreds of scalar loads and a dozen per-lane
-            // table loads out of the frame loop and spills them.  The body sees the arguments through an opaque
-            // copy of the kernel-argument segment pointer, refreshed per frame (layout: the parameter list above).
-            struct Args {
-                const float *in; void *out; int batch; int pad; const float4 *winb, *twT, *twB; const float2 *twC;
-                const SaIirLaneTab *lanetab; SaIirK ka;
-            };
-            typedef const Args __attribute__((address_space(4))) *ArgsPtr;
-            ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(ap));
-            const int fn = f + step < ap->batch ? f + step : -1;
-            chain_frame<NSEC, UNIT, OUT, WINGEN, true>(ap->in, ap->out, f, fn, first, smem, ap->winb, ap->twT, ap->twB, ap->twC,
-                                                       ap->lanetab, ap->ka);
-            if (fn < 0) break;
-            f = fn;
-            first = false;
-        }
-    } else {
-#ifdef SA_STAGGER
-        // probe: the first round of workgroups starts in lockstep (every CU loads, then every CU computes); delay
-        // the 2nd..4th workgroup of each CU by SA_STAGGER x 1.8 us each so that their phases interleave at once
-        if (blockIdx.x < 1024) {
-            const int k = (blockIdx.x >> 8) & 3;
-            for (int i = 0; i < k * SA_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
-        }
-#endif
-        chain_frame<NSEC, UNIT, OUT, WINGEN, false>(in, out, f, -1, true, smem, winb, twT, twB, twC, lanetab, ka);
-    }
+    chain_frame<NSEC, UNIT, OUT, WINGEN>(in, out, f, smem, winb, twT, twB, twC, lanetab, ka);
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
@@ -925,7 +738,7 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     if (f >= batch) return;
     v2f d[32];
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
-    stage_in_chunks<false, false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
+    stage_in_chunks<false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
     // Stage-out, the stage-in run backwards: each thread owns 64 consecutive samples, so storing straight
     // from the registers puts every lane of a store instruction into another 256-byte block (measured 5x
@@ -974,21 +787,6 @@ extern "C" int sa_debug_set_stamps(void *p)
 
 namespace {
 
-// Workgroups the device holds at once with this kernel's footprint: 4 per CU (35.6 KiB of LDS, 128 VGPRs).
-int resident_workgroups()
-{
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
-    int v = cached[dev].load(std::memory_order_relaxed);
-    if (v == 0) {
-        hipDeviceProp_t pr;
-        v = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? 4 * pr.multiProcessorCount : 1024;
-        cached[dev].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
-
 template <int NSEC, bool UNIT>
 hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK &ka,
                        hipStream_t stream)
@@ -997,34 +795,13 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
     hipError_t e = hipSuccess;
 #define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
-        auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0), false>                   \
-                              : chain_f32_kernel<NSEC, UNIT, OUTK, false, false>;                      \
+        auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0)>                          \
+                              : chain_f32_kernel<NSEC, UNIT, OUTK, false>;                             \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
         hipLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, \
                            tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
-    // Persistent form (IIR kernels writing all 16384 magnitudes): as many workgroups as the chip holds at once, each
-    // walking through its frames and requesting the next frame's first half ahead of its own last stores.
-    // OFF by default -- it is correct (bit-identical output) and measured SLOWER: 165 us against 133 us per 4096
-    // frames (profiles/r2_persistent_vs_dispatched.txt).  Workgroups that start together and never leave stay in
-    // lockstep: every frame then behaves like the first round of a launch, when all 1024 workgroups request their
-    // input at once and then all compute at once (first-round workgroups live 43 us, later ones 34 us).  The
-    // hardware dispatcher de-synchronises the workgroups for free by refilling slots as they drain.  Kept behind
-    // SA_PERSIST=1 so that the measurement can be repeated (tools/ab_libs.py lib.so:SA_PERSIST=1).
-    if constexpr (NSEC > 0) {
-        static const bool persist_on = std::getenv("SA_PERSIST") != nullptr;
-        const int resident = resident_workgroups();
-        if (out_kind == SA_OUT_MAG_FULL && persist_on && batch > resident) {
-            auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, true, true>
-                                  : chain_f32_kernel<NSEC, UNIT, SA_OUT_MAG_FULL, false, true>;
-            e = set_lds(kern);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(resident), block, kLdsBytes, stream, in, out, batch, tb.win_b, tb.twT, tb.twB, tb.twC,
-                               tb.lanetab, ka);
-            return hipGetLastError();
-        }
-    }
     switch (out_kind) {
         case SA_OUT_MAG_FULL: SA_LAUNCH(SA_OUT_MAG_FULL); break;
         case SA_OUT_MAG_HALF: SA_LAUNCH(SA_OUT_MAG_HALF); break;

@@ -883,7 +883,11 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
-    static const bool old_form = std::getenv("SA_Q7_OLD") != nullptr;       // A/B switch for tools/ab_q15.py
+#ifdef SA_Q7_OLD                       // A/B builds only (tools/ab_libs.py takes two libraries): the round-1 cascade
+    const bool old_form = true;
+#else
+    const bool old_form = false;
+#endif
     if (p.filter == SA_FILTER_WIDE) {
         hipLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
     } else if (p.filter == SA_FILTER_NONE || old_form) {

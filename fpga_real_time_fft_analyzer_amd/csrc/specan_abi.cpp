@@ -99,7 +99,7 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
                 for (int e = 0; e < 4; ++e)
                     lt->win_t[(g * 256 + t) * 4 + e] = (float)((double)half_win[64 * t + 4 * g + e] * gain);
     plan->wingen = 0;
-    if (half_win && cosw && !std::getenv("SA_NO_WINGEN")) {
+    if (half_win && cosw) {
         const double theta = 2.0 * M_PI / (double)(SA_NPTS - 1), S = 0.5 * gain;
         plan->wingen = 1;
         lt->wg0 = (float)(S * cosw[0]);
@@ -234,18 +234,42 @@ struct sa_handle {
     SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
     int16_t *d_rom = nullptr;
     uint2 *d_twq = nullptr;          // SA-FXFFT-1 twiddles, {(wr, wi), (-wi, wr)} packed int16 pairs
-    int16_t *d_work = nullptr;
-    int work_frames = 0;
+    // Q15 IIR workspace, one per launch slot (slot 0 = ordered mode; overlap mode uses slots 0..depth-1).  A
+    // workspace that is outgrown is retired, not freed (hipFree synchronises the whole device; launches in flight
+    // may still use it): freed in sa_destroy.  Growth is geometric so that the retired total stays below the live one.
+    static constexpr int kMaxOverlap = 4;
+    int16_t *d_work[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
+    int work_frames[kMaxOverlap] = {0, 0, 0, 0};
+    std::vector<void *> retired;
     // ---- stream-ordered control plane (no device-wide synchronisation anywhere after sa_create)
     // Table uploads run on the handle's own control stream: it first waits for everything the handle has
-    // launched so far (an event recorded on the data stream at upload time), copies from a pinned staging slot,
-    // and records `uploaded`; the next process call makes its stream wait for that event.  Other handles and
-    // other streams of the device are never stalled.
+    // launched so far, copies from a pinned staging slot, and records `uploaded`; the next process call makes its
+    // stream wait for that event.  Other handles and other streams of the device are never stalled.
+    // Ordering behind the handle's own launches: the stream of the most recent ordered-mode process call is
+    // remembered and the event `launched` is recorded on it when something has to wait for those launches (an
+    // upload, a stream switch, sa_destroy) -- not after every launch: a record per launch measured 1.3-2.7 % of the
+    // step (gpurun_out/ab_ov.log, round 3).  The caller may have destroyed that stream meanwhile (allowed once its
+    // work has completed, include/specan.h): the record then fails cleanly (the runtime checks the handle against
+    // its list of live streams), and mark_launched() falls back to one device synchronisation.
     hipStream_t ctl = nullptr;
     hipEvent_t launched = nullptr, uploaded = nullptr;
-    bool upload_pending = false;           // an upload was issued that the data stream has not waited for yet
-    hipStream_t data_stream = nullptr;     // stream of the most recent process call
-    bool have_data_stream = false;
+    bool launched_valid = false;           // `launched` covers every ordered-mode launch made so far
+    bool launches_unmarked = false;        // ordered-mode launches were made since `launched` was last recorded
+    unsigned upload_gen = 0;               // number of uploads issued so far
+    unsigned seen_gen = 0;                 // ordered mode: uploads the data stream has waited for
+    hipStream_t last_stream = nullptr;     // stream of the most recent ordered-mode process call
+    bool have_last_stream = false;
+    bool last_call_captured = false;       // that call was captured into a graph (see control_allowed)
+    // ---- overlapped launches (opt-in, sa_set_overlap): consecutive process calls alternate over `overlap` internal
+    // streams so that the tail of one launch runs under the head of the next; see include/specan.h
+    int overlap = 1;
+    hipStream_t ov_stream[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ov_fork[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ov_done[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
+    bool ov_used[kMaxOverlap] = {false, false, false, false};      // ov_done[i] has been recorded
+    bool ov_unjoined[kMaxOverlap] = {false, false, false, false};  // ... and no caller stream waits for it yet
+    unsigned ov_seen_gen[kMaxOverlap] = {0, 0, 0, 0};
+    unsigned long long ov_calls = 0;
     static constexpr int kStage = 4;       // pinned staging slots (a slot is reused after kStage uploads)
     void *stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t stage_done[kStage] = {nullptr, nullptr, nullptr, nullptr};
@@ -276,6 +300,41 @@ int fail(sa_handle *h, int code, const char *what, hipError_t e = hipSuccess)
 
 constexpr size_t kStageBytes = sizeof(SaIirLaneTab) > sizeof(float) * SA_NPTS ? sizeof(SaIirLaneTab) : sizeof(float) * SA_NPTS;
 
+// Control-plane calls change host state and device tables; a process call that is being captured into a hipGraph
+// has frozen the host part (kernel arguments) but not the tables, so such calls are refused while the capture of the
+// handle's most recent process call is still open.  Checked at the top of every control-plane entry point, before
+// anything is changed.  (The query touches the stream of a captured call only: that stream is alive while its
+// capture is open, and an error from the query -- capture ended, stream gone -- reads as "not capturing".)
+int control_allowed(sa_handle *h)
+{
+    if (!h->last_call_captured) return SA_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->last_stream, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        cs = hipStreamCaptureStatusNone;
+    }
+    if (cs != hipStreamCaptureStatusNone)
+        return fail(h, SA_ESTATE, "control-plane call while the handle's stream is being captured into a graph");
+    h->last_call_captured = false;
+    return SA_OK;
+}
+
+// Bring `launched` up to date with the handle's ordered-mode launches (see sa_handle).
+int mark_launched(sa_handle *h)
+{
+    if (!h->launches_unmarked) return SA_OK;
+    h->launches_unmarked = false;
+    if (!h->last_call_captured && hipEventRecord(h->launched, h->last_stream) == hipSuccess) {
+        h->launched_valid = true;
+        return SA_OK;
+    }
+    // the stream is gone (or was capturing: a captured record would tie the event to the graph): the launches on
+    // it cannot be named any more -- wait for the device once
+    (void)hipGetLastError();
+    SA_HIP(h, hipDeviceSynchronize());
+    return SA_OK;
+}
+
 // Stream-ordered table update (see sa_handle): after everything launched so far, before everything launched
 // later; asynchronous for the host except when all staging slots are still waiting for their copies.
 int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
@@ -286,36 +345,100 @@ int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
     h->stage_next = (slot + 1) % sa_handle::kStage;
     if (h->stage_used[slot]) SA_HIP(h, hipEventSynchronize(h->stage_done[slot]));   // that slot's old copy has run
     std::memcpy(h->stage[slot], src, bytes);
-    if (h->have_data_stream) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->data_stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(h, SA_ESTATE, "control-plane call while the handle's stream is being captured into a graph");
-        SA_HIP(h, hipEventRecord(h->launched, h->data_stream));
-        SA_HIP(h, hipStreamWaitEvent(h->ctl, h->launched, 0));
-    }
+    { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
+    if (h->launched_valid) SA_HIP(h, hipStreamWaitEvent(h->ctl, h->launched, 0));
+    for (int i = 0; i < sa_handle::kMaxOverlap; ++i)
+        if (h->ov_used[i]) SA_HIP(h, hipStreamWaitEvent(h->ctl, h->ov_done[i], 0));
     SA_HIP(h, hipMemcpyAsync(dst, h->stage[slot], bytes, hipMemcpyHostToDevice, h->ctl));
     SA_HIP(h, hipEventRecord(h->stage_done[slot], h->ctl));
     h->stage_used[slot] = true;
     SA_HIP(h, hipEventRecord(h->uploaded, h->ctl));
-    h->upload_pending = true;
+    ++h->upload_gen;
     return SA_OK;
 }
 
-// Called by every process entry point before it launches on `stream`: orders the launch after pending table
-// uploads and after the handle's earlier launches if the caller switched streams.
-int enter_stream(sa_handle *h, hipStream_t stream)
+// One process call = begin_call, launches on c.stream with workspace slot c.slot, end_call.
+//   ordered mode: c.stream is the caller's stream; the call is ordered after pending table uploads and, if the
+//     caller switched streams, after the handle's earlier launches; end_call records `launched` on it.
+//   overlap mode (sa_set_overlap(h, d), d > 1): call k runs on internal stream k % d behind a fork event taken from
+//     the caller's stream BEFORE that stream is made to wait for call k-d+1 (the join): kernel k depends on
+//     what the caller enqueued before call k, not on kernels k-1 .. k-d+1, and may run beside them.
+struct CallCtx {
+    hipStream_t stream;
+    int slot;
+    bool overlapped, captured;
+};
+
+int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
 {
-    if (h->have_data_stream && h->data_stream != stream) {
-        SA_HIP(h, hipEventRecord(h->launched, h->data_stream));
-        SA_HIP(h, hipStreamWaitEvent(stream, h->launched, 0));
-        h->upload_pending = true;            // the new stream has not seen the last upload either
+    c->stream = user;
+    c->slot = 0;
+    c->overlapped = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    SA_HIP(h, hipStreamIsCapturing(user, &cs));
+    c->captured = cs != hipStreamCaptureStatusNone;
+    if (h->overlap > 1) {
+        if (c->captured)
+            return fail(h, SA_ESTATE, "overlapped launches (sa_set_overlap > 1) cannot be captured into a graph");
+        const int d = h->overlap, slot = (int)(h->ov_calls % (unsigned)d);
+        SA_HIP(h, hipEventRecord(h->ov_fork[slot], user));
+        // join: the call issued d-1 calls ago (the next user of the oldest slot is the call after this one)
+        const int join = (slot + 1) % d;
+        if (h->ov_unjoined[join]) {
+            SA_HIP(h, hipStreamWaitEvent(user, h->ov_done[join], 0));
+            h->ov_unjoined[join] = false;
+        }
+        SA_HIP(h, hipStreamWaitEvent(h->ov_stream[slot], h->ov_fork[slot], 0));
+        // (ordered-mode launches made before the switch to overlap mode have completed: sa_set_overlap waited)
+        if (h->ov_seen_gen[slot] != h->upload_gen) {
+            SA_HIP(h, hipStreamWaitEvent(h->ov_stream[slot], h->uploaded, 0));
+            h->ov_seen_gen[slot] = h->upload_gen;
+        }
+        c->stream = h->ov_stream[slot];
+        c->slot = slot;
+        c->overlapped = true;
+        return SA_OK;
     }
-    if (h->upload_pending) {
-        SA_HIP(h, hipStreamWaitEvent(stream, h->uploaded, 0));
-        h->upload_pending = false;
+    if (h->have_last_stream && h->last_stream != user) {
+        { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
+        if (h->launched_valid) SA_HIP(h, hipStreamWaitEvent(user, h->launched, 0));
+        h->seen_gen = h->upload_gen - 1;     // the new stream has not seen the last upload either
     }
-    h->data_stream = stream;
-    h->have_data_stream = true;
+    if (h->seen_gen != h->upload_gen) {
+        if (h->upload_gen) SA_HIP(h, hipStreamWaitEvent(user, h->uploaded, 0));
+        h->seen_gen = h->upload_gen;
+    }
+    h->last_stream = user;
+    h->have_last_stream = true;
+    h->last_call_captured = c->captured;
+    return SA_OK;
+}
+
+int end_call(sa_handle *h, const CallCtx &c)
+{
+    if (c.overlapped) {
+        SA_HIP(h, hipEventRecord(h->ov_done[c.slot], c.stream));
+        h->ov_used[c.slot] = true;
+        h->ov_unjoined[c.slot] = true;
+        ++h->ov_calls;
+        return SA_OK;
+    }
+    h->launches_unmarked = true;         // recorded on demand (mark_launched)
+    return SA_OK;
+}
+
+// Workspace of a launch slot, grown without touching launches in flight (see sa_handle::retired).
+int ensure_work(sa_handle *h, int slot, int frames, bool captured)
+{
+    if (frames <= h->work_frames[slot]) return SA_OK;
+    if (captured) return fail(h, SA_ESTATE, "workspace growth inside a stream capture: call sa_reserve() first");
+    long want = frames, geo = (long)h->work_frames[slot] + h->work_frames[slot] / 2;
+    if (geo > want) want = geo;
+    void *p = nullptr;
+    SA_HIP(h, hipMalloc(&p, (size_t)want * SA_NPTS * sizeof(int16_t)));
+    if (h->d_work[slot]) h->retired.push_back(h->d_work[slot]);
+    h->d_work[slot] = (int16_t *)p;
+    h->work_frames[slot] = (int)want;
     return SA_OK;
 }
 
@@ -593,7 +716,15 @@ int sa_destroy(sa_handle *h)
 {
     if (!h) return SA_OK;
     (void)hipSetDevice(h->device);
-    if (h->have_data_stream) (void)hipStreamSynchronize(h->data_stream);     // this handle's work only
+    // this handle's work only (the caller's last stream may be gone already: mark_launched copes)
+    (void)mark_launched(h);
+    if (h->launched_valid) (void)hipEventSynchronize(h->launched);
+    for (int i = 0; i < sa_handle::kMaxOverlap; ++i) {
+        if (h->ov_stream[i]) (void)hipStreamSynchronize(h->ov_stream[i]);
+        if (h->ov_fork[i]) (void)hipEventDestroy(h->ov_fork[i]);
+        if (h->ov_done[i]) (void)hipEventDestroy(h->ov_done[i]);
+        if (h->ov_stream[i]) (void)hipStreamDestroy(h->ov_stream[i]);
+    }
     if (h->ctl) (void)hipStreamSynchronize(h->ctl);
     for (int i = 0; i < sa_handle::kStage; ++i) {
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -611,7 +742,8 @@ int sa_destroy(sa_handle *h)
     (void)hipFree(h->d_lt_custom);
     (void)hipFree(h->d_rom);
     (void)hipFree(h->d_twq);
-    (void)hipFree(h->d_work);
+    for (int i = 0; i < sa_handle::kMaxOverlap; ++i) (void)hipFree(h->d_work[i]);
+    for (void *p : h->retired) (void)hipFree(p);
     delete h;
     return SA_OK;
 }
@@ -620,14 +752,59 @@ int sa_reserve(sa_handle *h, int max_batch)
 {
     if (!h) return SA_EINVAL;
     if (max_batch < 0) return fail(h, SA_ESHAPE, "sa_reserve: negative batch");
-    if (max_batch <= h->work_frames) return SA_OK;
     SA_HIP(h, hipSetDevice(h->device));
-    if (h->have_data_stream) SA_HIP(h, hipStreamSynchronize(h->data_stream));    // launches that use the old workspace
-    if (h->d_work) SA_HIP(h, hipFree(h->d_work));
-    h->d_work = nullptr;
-    h->work_frames = 0;
-    SA_HIP(h, hipMalloc(&h->d_work, (size_t)max_batch * SA_NPTS * sizeof(int16_t)));
-    h->work_frames = max_batch;
+    for (int i = 0; i < h->overlap; ++i) {
+        const int rc = ensure_work(h, i, max_batch, false);
+        if (rc != SA_OK) return rc;
+    }
+    return SA_OK;
+}
+
+int sa_set_overlap(sa_handle *h, int depth)
+{
+    if (!h) return SA_EINVAL;
+    if (depth < 1 || depth > sa_handle::kMaxOverlap) return fail(h, SA_EINVAL, "sa_set_overlap: depth must be 1..4");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
+    if (depth == h->overlap) return SA_OK;
+    SA_HIP(h, hipSetDevice(h->device));
+    // leave the old mode with nothing of the handle's in flight (host wait on the handle's own work only)
+    { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
+    if (h->launched_valid) SA_HIP(h, hipEventSynchronize(h->launched));
+    for (int i = 0; i < sa_handle::kMaxOverlap; ++i) {
+        if (h->ov_used[i]) SA_HIP(h, hipEventSynchronize(h->ov_done[i]));
+        h->ov_unjoined[i] = false;
+    }
+    for (int i = 0; i < depth; ++i) {
+        if (!h->ov_stream[i]) SA_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[i], hipStreamNonBlocking));
+        if (!h->ov_fork[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_fork[i], hipEventDisableTiming));
+        if (!h->ov_done[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_done[i], hipEventDisableTiming));
+        // every slot starts with the workspace the handle already has somewhere
+        int most = 0;
+        for (int j = 0; j < sa_handle::kMaxOverlap; ++j) most = h->work_frames[j] > most ? h->work_frames[j] : most;
+        const int rc = ensure_work(h, i, most, false);
+        if (rc != SA_OK) return rc;
+    }
+    h->overlap = depth;
+    h->ov_calls = 0;
+    return SA_OK;
+}
+
+int sa_get_overlap(const sa_handle *h, int *depth)
+{
+    if (!h || !depth) return SA_EINVAL;
+    *depth = h->overlap;
+    return SA_OK;
+}
+
+int sa_flush(sa_handle *h, void *stream)
+{
+    if (!h) return SA_EINVAL;
+    SA_HIP(h, hipSetDevice(h->device));
+    for (int i = 0; i < sa_handle::kMaxOverlap; ++i)
+        if (h->ov_unjoined[i]) {
+            SA_HIP(h, hipStreamWaitEvent((hipStream_t)stream, h->ov_done[i], 0));
+            h->ov_unjoined[i] = false;
+        }
     return SA_OK;
 }
 
@@ -636,6 +813,7 @@ int sa_set_filter_mode(sa_handle *h, uint8_t cmd)
     if (!h) return SA_EINVAL;
     if (cmd != SA_FILTER_DEFAULT && cmd != SA_FILTER_CUSTOM && cmd != SA_FILTER_NONE && cmd != SA_FILTER_WIDE)
         return fail(h, SA_EINVAL, "sa_set_filter_mode: not a filter-select byte (0x00, 0xA1, 0xB1, 0xA2)");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     h->filter_mode = cmd;
     return SA_OK;
 }
@@ -651,6 +829,7 @@ int sa_load_coeffs_q7(sa_handle *h, const int8_t c[12])
 {
     if (!h) return SA_EINVAL;
     if (!c) return fail(h, SA_EINVAL, "sa_load_coeffs_q7: NULL coefficients");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     std::memcpy(h->c12_custom, c, 12);
     double sos[36];
     sos_from_q7(h->c12_custom, sos);
@@ -668,6 +847,7 @@ int sa_feed_command_bytes_ex(sa_handle *h, const uint8_t *bytes, size_t n, sa_cm
 {
     if (!h) return SA_EINVAL;
     if (!bytes && n) return fail(h, SA_EINVAL, "sa_feed_command_bytes: NULL bytes");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     for (size_t i = 0; i < n; ++i) {
         const uint8_t b = bytes[i];
         if (h->rx_count >= 0) {                      // ACQUIRE: busy, byte is a coefficient; neither command_control
@@ -729,6 +909,7 @@ int sa_load_sos_f64(sa_handle *h, const double *sos, int n_sections)
     if (!h) return SA_EINVAL;
     if (!sos) return fail(h, SA_EINVAL, "sa_load_sos: NULL sos");
     if (n_sections < 0 || n_sections > SA_MAXSEC) return fail(h, SA_EINVAL, "sa_load_sos: 0..6 sections");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     double norm[36];
     for (int s = 0; s < n_sections; ++s) {
         const double a0 = sos[6 * s + 3];
@@ -753,6 +934,7 @@ int sa_load_sos_q14(sa_handle *h, const int16_t *sos, int n_sections)
     if (!h) return SA_EINVAL;
     if (!sos) return fail(h, SA_EINVAL, "sa_load_sos_q14: NULL sos");
     if (n_sections < 0 || n_sections > SA_MAXSEC) return fail(h, SA_EINVAL, "sa_load_sos_q14: 0..6 sections");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     std::memset(h->sos_q14, 0, sizeof h->sos_q14);
     std::memcpy(h->sos_q14, sos, sizeof(int16_t) * 6 * n_sections);
     h->nsec_q14 = n_sections;
@@ -762,6 +944,7 @@ int sa_load_sos_q14(sa_handle *h, const int16_t *sos, int n_sections)
 int sa_set_window_q15(sa_handle *h, const int16_t *w)
 {
     if (!h) return SA_EINVAL;
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     if (w) h->rom.assign(w, w + SA_NPTS); else default_rom(h->rom);
     return upload(h, h->d_rom, h->rom.data(), sizeof(int16_t) * SA_NPTS);
 }
@@ -776,6 +959,7 @@ int sa_get_window_q15(const sa_handle *h, int16_t *w)
 int sa_set_window_f32(sa_handle *h, const float *w)
 {
     if (!h) return SA_EINVAL;
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     if (w) return set_window_f32_from(h, w);
     std::vector<double> d;
     default_window_f64(d);
@@ -790,6 +974,7 @@ int sa_set_window_mode_q15(sa_handle *h, int mode)
 {
     if (!h) return SA_EINVAL;
     if (mode != SA_WIN_RTL_SIGNED && mode != SA_WIN_HANN_U16) return fail(h, SA_EINVAL, "sa_set_window_mode_q15: bad mode");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     h->win_mode_q15 = mode;
     return SA_OK;
 }
@@ -814,12 +999,13 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
     if (batch == 0) return SA_OK;
     if (!in || !out_time) return fail(h, SA_EINVAL, "sa_filter_q15: NULL tensor");
     SA_HIP(h, hipSetDevice(h->device));
-    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
+    CallCtx c;
+    { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
-    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, (hipStream_t)stream));
-    return SA_OK;
+    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream));
+    return end_call(h, c);
 }
 
 int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, void *stream)
@@ -829,21 +1015,19 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     if (batch == 0) return SA_OK;
     if (!in || !out_iq) return fail(h, SA_EINVAL, "sa_process_q15: NULL tensor");
     SA_HIP(h, hipSetDevice(h->device));
-    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
+    CallCtx c;
+    { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
     if (p.filter == SA_FILTER_NONE) {
-        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, (hipStream_t)stream));
-        return SA_OK;
+        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream));
+        return end_call(h, c);
     }
-    if (batch > h->work_frames) {
-        const int rc = sa_reserve(h, batch);
-        if (rc != SA_OK) return rc;
-    }
-    SA_HIP(h, sa_launch_filter_q15(in, h->d_work, batch, p, t, (hipStream_t)stream));
-    SA_HIP(h, sa_launch_fft_q15(h->d_work, out_iq, batch, false, p, t, (hipStream_t)stream));
-    return SA_OK;
+    { const int rc = ensure_work(h, c.slot, batch, c.captured); if (rc != SA_OK) return rc; }
+    SA_HIP(h, sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream));
+    SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream));
+    return end_call(h, c);
 }
 
 int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_kind, void *stream)
@@ -856,7 +1040,8 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     if (h->filter_mode == SA_FILTER_WIDE)
         return fail(h, SA_ESTATE, "sa_process_f32: filter mode 0xA2 (Q2.14) belongs to the Q15 path; use 0xA1 with sa_load_sos_f32");
     SA_HIP(h, hipSetDevice(h->device));
-    { const int rc = enter_stream(h, (hipStream_t)stream); if (rc != SA_OK) return rc; }
+    CallCtx c;
+    { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     // The section coefficients and predictor taps travel by value in the kernel arguments (stream-ordered
     // by construction); the per-lane matrices and the window live in device memory (stream-ordered uploads).
     SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr};
@@ -867,8 +1052,8 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
     }
-    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, (hipStream_t)stream));
-    return SA_OK;
+    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream));
+    return end_call(h, c);
 }
 
 int sa_pack_frame(const int16_t *iq_host, uint8_t *frame_bytes)

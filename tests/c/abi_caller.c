@@ -114,9 +114,30 @@ int main(int argc, char **argv)
         fprintf(stderr, "bad arguments were not rejected\n");
         return 1;
     }
+    /* Stream lifetime: the library may use a stream only inside the call that passed it.  Destroy stream A right
+     * after its work, run the same batch on a new stream B, then upload a table (default ROM again) and run once
+     * more: every result equals the first one, and sa_destroy() comes after the last stream is gone. */
+    {
+        hipStream_t sb;
+        int16_t *iq2 = (int16_t *)malloc(n_out * sizeof(int16_t));
+        CHECK_HIP(hipStreamDestroy(stream));
+        CHECK_HIP(hipStreamCreate(&sb));
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) CHECK_SA(sa_set_window_q15(h, NULL));
+            CHECK_HIP(hipMemsetAsync(d_out, 0, n_out * sizeof(int16_t), sb));
+            CHECK_SA(sa_process_q15(h, d_in, d_out, nframes, (void *)sb));
+            CHECK_HIP(hipMemcpyAsync(iq2, d_out, n_out * sizeof(int16_t), hipMemcpyDeviceToHost, sb));
+            CHECK_HIP(hipStreamSynchronize(sb));
+            if (memcmp(iq, iq2, n_out * sizeof(int16_t)) != 0) {
+                fprintf(stderr, "results changed after the first stream was destroyed (pass %d)\n", pass);
+                return 1;
+            }
+        }
+        CHECK_HIP(hipStreamDestroy(sb));
+        free(iq2);
+    }
     hipFree(d_in);
     hipFree(d_out);
-    hipStreamDestroy(stream);
     sa_destroy(h);
     free(x); free(iq); free(frame);
     return 0;

@@ -23,7 +23,7 @@ def test_header_declares_the_boundary():
 def test_library_exports_every_declared_symbol(hip_lib_built):
     for name in declared_symbols():
         assert hasattr(hip_lib_built, name), f"{name} declared in include/specan.h but not exported"
-    assert hip_lib_built.sa_abi_version() == 2
+    assert hip_lib_built.sa_abi_version() == 3
 
 
 def test_no_torch_or_oracle_linkage(hip_lib_built):
@@ -43,6 +43,19 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, fn)).read()
                 for bad in ("import oracle", "from oracle", "libspecan_oracle", "oracle/specan_oracle.c\"", "oracle.oracle"):
                     assert bad not in txt, (fn, bad)
+
+
+def test_no_environment_switches_in_the_product():
+    """Which kernel the product library launches never depends on the environment: A/B variants are -D builds
+    (tools/ab_libs.py takes two libraries).  No getenv anywhere under csrc/, nor in the built library's imports."""
+    csrc = os.path.join(ROOT, "fpga_real_time_fft_analyzer_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".cpp", ".hip", ".hpp", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
+    from fpga_real_time_fft_analyzer_amd import abi
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", abi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_create_without_gpu_fails_loudly(hip_lib_built):

@@ -52,7 +52,7 @@ def test_build_then_smoke_in_one_process():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import __graft_entry__ as g; from fpga_real_time_fft_analyzer_amd import abi; "
-            "assert abi.lib().sa_abi_version() == 2; g.smoke()")
+            "assert abi.lib().sa_abi_version() == 3; g.smoke()")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "smoke ok" in r.stdout
@@ -203,6 +203,97 @@ def test_custom_window_and_restore(ch, torch_mod, oracle):
     _, _, mag = oracle.chain_fp(x, None)
     got = ch.process_f32(_dev(torch_mod, x)).cpu().numpy()
     assert rel_maxnorm(got, mag) <= TOL
+
+
+@pytest.mark.parametrize("wname", ["blackman", "hamming"])
+def test_table_and_fitted_windows_through_the_iir(ch, torch_mod, oracle, wname):
+    """The window is a loadable ROM (new/hann.vhd:5-6, new/hann8192.vhd:34-41).  Blackman does not fit
+    a0 - a1 cos: the IIR kernels read the gain-folded table (WINGEN = false x NSEC 6 / 4 / 2); Hamming fits with
+    a0 != a1: the in-place generator with other constants than Hann's.  12th-order Butterworth in mode 0xA1, all
+    output kinds; then shorter cascades; then the default window again."""
+    torch = torch_mod
+    g = load_golden("g2_config1.npz")
+    w = (np.blackman(N) if wname == "blackman" else np.hamming(N)).astype(np.float32)
+    x = synth(5, seed=77)
+    xd = _dev(torch, x)
+    ch.set_window_f32(w)
+    ch.load_sos(g["sos"])
+    ch.set_filter_mode(0xA1)
+    y, X, mag = oracle.chain_fp(x, g["sos"], hann=w.astype(np.float64))
+    H = N // 2 + 1
+    assert rel_maxnorm(ch.process_f32(xd, out_kind="mag_full").cpu().numpy(), mag) <= TOL
+    assert rel_maxnorm(ch.process_f32(xd, out_kind="mag_half").cpu().numpy(), mag[:, :H]) <= TOL
+    spec = ch.process_f32(xd, out_kind="spec_half").cpu().numpy()
+    assert (np.abs(spec - X).max(axis=1) <= TOL * np.abs(X).max(axis=1)).all()
+    seq = max(rel_maxnorm(oracle.sosfilt_f32_c(g["sos"], (x[i].astype(np.float64) * w).astype(np.float32))[None, :], y[i][None, :])
+              for i in range(x.shape[0]))
+    assert rel_maxnorm(ch.process_f32(xd, out_kind="time").cpu().numpy(), y) <= max(TOL, 2 * seq)
+    # 4- and 2-section cascades (the other compiled section counts) with the same window
+    from scipy import signal
+    for order, kind in ((8, "lowpass"), (4, "highpass"), (3, "lowpass")):
+        sos = signal.butter(order, 0.3, kind, output="sos")
+        ch.load_sos(sos)
+        _, _, m = oracle.chain_fp(x, sos, hann=w.astype(np.float64))
+        assert rel_maxnorm(ch.process_f32(xd, out_kind="mag_half").cpu().numpy(), m[:, :H]) <= TOL, (order, kind)
+    # a non-unit-numerator cascade (band-pass: b = [1, 0, -1]) on the same window
+    sos = signal.butter(4, [0.1, 0.3], "bandpass", output="sos")
+    ch.load_sos(sos)
+    _, _, m = oracle.chain_fp(x, sos, hann=w.astype(np.float64))
+    assert rel_maxnorm(ch.process_f32(xd, out_kind="mag_half").cpu().numpy(), m[:, :H]) <= TOL
+    # default window again (Hann: the generator path with a0 = a1 = 0.5)
+    ch.set_window_f32(None)
+    ch.load_sos(g["sos"])
+    _, _, mag = oracle.chain_fp(x, g["sos"])
+    assert rel_maxnorm(ch.process_f32(xd, out_kind="mag_half").cpu().numpy(), mag[:, :H]) <= TOL
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_overlapped_launches_contract(ch, torch_mod, oracle, depth):
+    """sa_set_overlap: consecutive calls may run beside each other (frames are independent: the reference resets
+    the filter state per frame, new/filter_iir12_cust.vhd:48-63).  Outputs are bit-identical to the ordered mode,
+    the results of call k are visible on the caller's stream after call k+depth-1 or after flush(), control-plane
+    calls stay ordered between calls, and capture is refused."""
+    torch = torch_mod
+    g = load_golden("g2_config1.npz")
+    ch.load_sos(g["sos"])
+    ch.set_filter_mode(0xA1)
+    xs = [_dev(torch, synth(64, seed=100 + i)) for i in range(6)]
+    ref = [ch.process_f32(x).clone() for x in xs]                 # ordered mode
+    ch.set_filter_mode(0xB1)
+    ref_bypass = ch.process_f32(xs[5]).clone()
+    ch.set_filter_mode(0xA1)
+    torch.cuda.synchronize()
+    assert ch.overlap == 1
+    ch.set_overlap(depth)
+    assert ch.overlap == depth
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        outs = [torch.zeros_like(ref[0]) for _ in xs]
+        seen = []
+        for k in range(5):
+            ch.process_f32(xs[k], out=outs[k])
+            if k >= depth - 1:                                   # call k-depth+1 is joined now: read it on the stream
+                seen.append((k - depth + 1, outs[k - depth + 1].clone()))
+        ch.set_filter_mode(0xB1)                                 # control plane between overlapped calls
+        ch.process_f32(xs[5], out=outs[5])
+        ch.flush()
+        tail = [o.clone() for o in outs]
+    s.synchronize()
+    for k, got in seen:
+        assert torch.equal(got, ref[k]), k
+    for k in range(5):
+        assert torch.equal(tail[k], ref[k]), k
+    assert torch.equal(tail[5], ref_bypass)
+    # not capturable in this mode; ordered mode still is
+    from fpga_real_time_fft_analyzer_amd.abi import SpecanError
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(SpecanError):
+        with torch.cuda.graph(graph):
+            ch.process_f32(xs[0], out=outs[0])
+    torch.cuda.synchronize()
+    ch.set_overlap(1)
+    ch.set_filter_mode(0xA1)
+    assert torch.equal(ch.process_f32(xs[0]), ref[0])
 
 
 def test_edge_inputs(ch, torch_mod):

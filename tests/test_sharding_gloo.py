@@ -69,7 +69,7 @@ def test_shard_helper_edges():
 def _run_bench(args, env_extra, timeout=300):
     import json
     import subprocess
-    env = dict(os.environ, SA_BENCH_STUB="1", **env_extra)
+    env = dict(os.environ, SA_BENCH_STUB="1", SA_BENCH_CPU_SECONDS="0.3", **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         if k not in env_extra:
             env.pop(k, None)
@@ -94,6 +94,12 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert line["ms_per_step"] >= 4.0
     assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"]
     assert "roofline" not in line and line["data"].startswith("stub")
+    # the CPU baseline of the same run sits beside the N > 1 line too (measured by the launcher before the ranks
+    # start, on the same host cores), and rank 0 reports every rank's kernel time (launch skew between GPUs)
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1
+    assert line["per_rank_kernel_ms"] == [2.0, 4.0]
+    assert line["launches_in_flight"] == 2
 
 
 def test_bench_under_torchrun_env_and_mismatch():
@@ -105,13 +111,14 @@ def test_bench_under_torchrun_env_and_mismatch():
     assert rc == 2 and not lines and "WORLD_SIZE" in err
     port = _free_port()
     import subprocess
-    envs = [dict(os.environ, SA_BENCH_STUB="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+    envs = [dict(os.environ, SA_BENCH_STUB="1", SA_BENCH_CPU_SECONDS="0.3", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(2)]
     ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                            env=e, stdout=subprocess.PIPE, text=True) for e in envs]
     outs = [p.communicate(timeout=300)[0] for p in ps]
     assert all(p.returncode == 0 for p in ps)
     assert '"n_gpus": 2' in outs[0] and "{" not in outs[1]              # only rank 0 prints the JSON line
+    assert '"cpu_baseline"' in outs[0] and '"per_rank_kernel_ms": [2.0, 4.0]' in outs[0]    # rank 0 measured it itself
     # ... and nothing else reaches stdout (gloo announces its connections there unless the bench keeps it away)
     assert len(outs[0].strip().splitlines()) == 1 and outs[1].strip() == ""
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of alternative builds of the library in one process, interleaved rounds.
-usage: ab_libs.py libA.so libB.so ...   (paths relative to the package dir)"""
+usage: ab_libs.py libA.so libB.so[@ovD] ...   (paths relative to the package dir; "@ov2" = overlap depth 2 on that
+handle, sa_set_overlap: timed with a flush before the final synchronisation)"""
 import ctypes as C
 import os
 import sys
@@ -28,6 +29,10 @@ libs = []
 for name in sys.argv[1:]:
     # "lib.so:VAR=value" sets an environment variable while that library's handle is created (plan-time switches)
     envset = None
+    depth = 1
+    if "@ov" in name:
+        name, d = name.split("@ov", 1)
+        depth = int(d)
     if ":" in name:
         name, envset = name.split(":", 1)
         k, v = envset.split("=", 1)
@@ -42,6 +47,11 @@ for name in sys.argv[1:]:
     if envset:
         del os.environ[envset.split("=", 1)[0]]
         name = name + ":" + envset
+    if depth > 1:
+        L.sa_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.sa_flush.argtypes = [C.c_void_p, C.c_void_p]
+        assert L.sa_set_overlap(h, depth) == 0
+        name = f"{name}@ov{depth}"
     libs.append((name, L, h))
 st = torch.cuda.current_stream().cuda_stream
 ROUNDS, REPS = 12, 40
@@ -70,6 +80,8 @@ for mode in (0xA1, 0xB1):
             t0 = time.perf_counter()
             for i in range(REPS):
                 L.sa_process_f32(h, xs[i % ROT].data_ptr(), outs[i % ROT].data_ptr(), B, 0, st)
+            if "@ov" in name:
+                L.sa_flush(h, st)
             torch.cuda.synchronize()
             res.setdefault(name, []).append((time.perf_counter() - t0) / REPS)
     for name, _, _ in libs:
