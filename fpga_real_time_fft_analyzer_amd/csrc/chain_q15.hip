@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 }  // namespace
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                const SaQ15Tables &t, hipStream_t stream)
+                                const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
@@ -889,19 +889,20 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
     const bool old_form = false;
 #endif
     if (p.filter == SA_FILTER_WIDE) {
-        hipLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
+        hipExtLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, nullptr, stop, 0, in, out_time, batch, p, t.rom);
     } else if (p.filter == SA_FILTER_NONE || old_form) {
-        hipLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, in, out_time, batch, p, t.rom);
+        hipExtLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, nullptr, stop, 0, in, out_time, batch, p, t.rom);
     } else {
         const int per_wg = kFramesPerWave * kV2Waves;
-        hipLaunchKernelGGL(filter_q7_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, in, out_time,
+        hipExtLaunchKernelGGL(filter_q7_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr, stop, 0, in,
+                              out_time,
                            batch, p, t.rom);
     }
     return hipGetLastError();
 }
 
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
-                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream)
+                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid(batch), block(kFftWide);
@@ -909,6 +910,6 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     auto k = apply_window ? fft_q15_kernel<true> : fft_q15_kernel<false>;
     const hipError_t e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, in_time, out_iq, batch, p, t.rom, t.tw);
+    hipExtLaunchKernelGGL(k, grid, block, lds, stream, nullptr, stop, 0, in_time, out_iq, batch, p, t.rom, t.tw);
     return hipGetLastError();
 }

@@ -1,6 +1,7 @@
 // sa_common.hpp -- types shared by the host side of the C ABI and the HIP kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define SA_NPTS 16384          // real samples per frame
@@ -98,8 +99,10 @@ struct SaF32Tables {
     const SaIirK *iir;             // HOST pointer, copied into the kernel arguments (null = no IIR)
 };
 
+// `stop` (may be null): an event bound to the completion of the call's LAST kernel (hipExtLaunchKernel attaches it to
+// the dispatch packet itself: no marker packet between two launches, unlike hipEventRecord after the launch).
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
-                               hipStream_t stream);
+                               hipStream_t stream, hipEvent_t stop);
 
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM
@@ -107,6 +110,6 @@ struct SaQ15Tables {
 };
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                const SaQ15Tables &t, hipStream_t stream);
+                                const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
-                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream);
+                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);

@@ -245,16 +245,16 @@ struct sa_handle {
     // Table uploads run on the handle's own control stream: it first waits for everything the handle has
     // launched so far, copies from a pinned staging slot, and records `uploaded`; the next process call makes its
     // stream wait for that event.  Other handles and other streams of the device are never stalled.
-    // Ordering behind the handle's own launches: the stream of the most recent ordered-mode process call is
-    // remembered and the event `launched` is recorded on it when something has to wait for those launches (an
-    // upload, a stream switch, sa_destroy) -- not after every launch: a record per launch measured 1.3-2.7 % of the
-    // step (gpurun_out/ab_ov.log, round 3).  The caller may have destroyed that stream meanwhile (allowed once its
-    // work has completed, include/specan.h): the record then fails cleanly (the runtime checks the handle against
-    // its list of live streams), and mark_launched() falls back to one device synchronisation.
+    // Ordering behind the handle's own launches: the event `launched` is bound to the completion of the last kernel
+    // of every ordered-mode process call (hipExtLaunchKernel's stop event: it rides on the dispatch packet, where a
+    // hipEventRecord after the launch puts a marker packet between two launches and measured 1.3-2.7 % of the step,
+    // gpurun_out/ab_ov.log).  Uploads, stream switches and sa_destroy wait for that event; the caller's stream is
+    // never touched after the call that passed it has returned, so the caller may destroy it at any time (touching
+    // a destroyed stream crashes inside the runtime: gpurun_out/gpu_tests_b.log).  `last_stream` is compared, never
+    // dereferenced -- except for the capture query of control_allowed(), on a stream whose capture is open.
     hipStream_t ctl = nullptr;
     hipEvent_t launched = nullptr, uploaded = nullptr;
-    bool launched_valid = false;           // `launched` covers every ordered-mode launch made so far
-    bool launches_unmarked = false;        // ordered-mode launches were made since `launched` was last recorded
+    bool launched_valid = false;           // `launched` has been bound to a launch at least once
     unsigned upload_gen = 0;               // number of uploads issued so far
     unsigned seen_gen = 0;                 // ordered mode: uploads the data stream has waited for
     hipStream_t last_stream = nullptr;     // stream of the most recent ordered-mode process call
@@ -319,22 +319,6 @@ int control_allowed(sa_handle *h)
     return SA_OK;
 }
 
-// Bring `launched` up to date with the handle's ordered-mode launches (see sa_handle).
-int mark_launched(sa_handle *h)
-{
-    if (!h->launches_unmarked) return SA_OK;
-    h->launches_unmarked = false;
-    if (!h->last_call_captured && hipEventRecord(h->launched, h->last_stream) == hipSuccess) {
-        h->launched_valid = true;
-        return SA_OK;
-    }
-    // the stream is gone (or was capturing: a captured record would tie the event to the graph): the launches on
-    // it cannot be named any more -- wait for the device once
-    (void)hipGetLastError();
-    SA_HIP(h, hipDeviceSynchronize());
-    return SA_OK;
-}
-
 // Stream-ordered table update (see sa_handle): after everything launched so far, before everything launched
 // later; asynchronous for the host except when all staging slots are still waiting for their copies.
 int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
@@ -345,7 +329,6 @@ int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
     h->stage_next = (slot + 1) % sa_handle::kStage;
     if (h->stage_used[slot]) SA_HIP(h, hipEventSynchronize(h->stage_done[slot]));   // that slot's old copy has run
     std::memcpy(h->stage[slot], src, bytes);
-    { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
     if (h->launched_valid) SA_HIP(h, hipStreamWaitEvent(h->ctl, h->launched, 0));
     for (int i = 0; i < sa_handle::kMaxOverlap; ++i)
         if (h->ov_used[i]) SA_HIP(h, hipStreamWaitEvent(h->ctl, h->ov_done[i], 0));
@@ -365,6 +348,7 @@ int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
 //     what the caller enqueued before call k, not on kernels k-1 .. k-d+1, and may run beside them.
 struct CallCtx {
     hipStream_t stream;
+    hipEvent_t stop;          // bound to the call's last kernel by the launcher (null inside a stream capture)
     int slot;
     bool overlapped, captured;
 };
@@ -395,12 +379,12 @@ int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
             h->ov_seen_gen[slot] = h->upload_gen;
         }
         c->stream = h->ov_stream[slot];
+        c->stop = h->ov_done[slot];
         c->slot = slot;
         c->overlapped = true;
         return SA_OK;
     }
     if (h->have_last_stream && h->last_stream != user) {
-        { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
         if (h->launched_valid) SA_HIP(h, hipStreamWaitEvent(user, h->launched, 0));
         h->seen_gen = h->upload_gen - 1;     // the new stream has not seen the last upload either
     }
@@ -411,19 +395,23 @@ int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
     h->last_stream = user;
     h->have_last_stream = true;
     h->last_call_captured = c->captured;
+    // a captured record would tie the event to the graph; replays are ordered by the caller (include/specan.h)
+    c->stop = c->captured ? nullptr : h->launched;
+#ifdef SA_AB_NO_STOP_EVENT               // A/B builds only: prices the stop event of the ordered mode
+    c->stop = nullptr;
+#endif
     return SA_OK;
 }
 
 int end_call(sa_handle *h, const CallCtx &c)
 {
     if (c.overlapped) {
-        SA_HIP(h, hipEventRecord(h->ov_done[c.slot], c.stream));
         h->ov_used[c.slot] = true;
         h->ov_unjoined[c.slot] = true;
         ++h->ov_calls;
         return SA_OK;
     }
-    h->launches_unmarked = true;         // recorded on demand (mark_launched)
+    if (!c.captured) h->launched_valid = true;
     return SA_OK;
 }
 
@@ -716,8 +704,7 @@ int sa_destroy(sa_handle *h)
 {
     if (!h) return SA_OK;
     (void)hipSetDevice(h->device);
-    // this handle's work only (the caller's last stream may be gone already: mark_launched copes)
-    (void)mark_launched(h);
+    // this handle's work only, through handle-owned objects (the caller's streams may be gone already)
     if (h->launched_valid) (void)hipEventSynchronize(h->launched);
     for (int i = 0; i < sa_handle::kMaxOverlap; ++i) {
         if (h->ov_stream[i]) (void)hipStreamSynchronize(h->ov_stream[i]);
@@ -768,7 +755,6 @@ int sa_set_overlap(sa_handle *h, int depth)
     if (depth == h->overlap) return SA_OK;
     SA_HIP(h, hipSetDevice(h->device));
     // leave the old mode with nothing of the handle's in flight (host wait on the handle's own work only)
-    { const int rc = mark_launched(h); if (rc != SA_OK) return rc; }
     if (h->launched_valid) SA_HIP(h, hipEventSynchronize(h->launched));
     for (int i = 0; i < sa_handle::kMaxOverlap; ++i) {
         if (h->ov_used[i]) SA_HIP(h, hipEventSynchronize(h->ov_done[i]));
@@ -1004,7 +990,7 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
-    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream));
+    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream, c.stop));
     return end_call(h, c);
 }
 
@@ -1021,12 +1007,12 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
     if (p.filter == SA_FILTER_NONE) {
-        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream));
+        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream, c.stop));
         return end_call(h, c);
     }
     { const int rc = ensure_work(h, c.slot, batch, c.captured); if (rc != SA_OK) return rc; }
-    SA_HIP(h, sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream));
-    SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream));
+    SA_HIP(h, sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr));
+    SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream, c.stop));
     return end_call(h, c);
 }
 
@@ -1052,7 +1038,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
     }
-    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream));
+    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, c.stop));
     return end_call(h, c);
 }
 

@@ -26,11 +26,10 @@
  *     (a window or coefficient upload may block the HOST briefly when more than four uploads are
  *     still waiting for their copies; a Q15 workspace that is outgrown is kept until sa_destroy()
  *     rather than freed, because hipFree synchronises the device).
- *   - stream lifetime: a stream passed to a process call may be destroyed once the work queued on
- *     it has completed (synchronise it first), in any order with later calls and sa_destroy().  The
- *     handle remembers the stream of its most recent ordered-mode call to order uploads, stream
- *     switches and sa_destroy() behind its launches; if that stream is gone by then, it falls back
- *     to one device synchronisation instead of failing.
+ *   - stream lifetime: the library uses the stream passed to a process call only inside that call.
+ *     The caller may destroy it afterwards, in any order with later calls and sa_destroy(): uploads,
+ *     stream switches and sa_destroy() order themselves behind an event the handle owns, bound to
+ *     the completion of the call's last kernel.
  *   - hipGraph capture: process calls are capturable in ordered mode once sa_reserve() has sized
  *     the workspace.  A captured call freezes the control state of capture time in its kernel
  *     arguments; control-plane calls are refused (SA_ESTATE, nothing changed) while that capture
