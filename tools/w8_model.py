@@ -46,19 +46,25 @@ def model(x):
     for t in range(T):
         u = t >> 1
         A[t] = fft16_dit(a_in[t]) * np.exp(-2j * np.pi * np.arange(16) * u / 4096)
-    # ---- exchange A -> B (two rounds by k1 half); pass-B thread tb = 32 k1 + 16 p + b
-    b_in = np.zeros((T, 16), complex)
+    # ---- exchange A -> B, two rounds; every thread hands over eight values and takes eight in per round (registers
+    #      and LDS hold the data exactly once): round q pairs writer half (t >> 8) and reader half (tb >> 8) that
+    #      differ by q.  Registers modelled in place: a value is gone once written, bq fills up over the two rounds.
+    b_in = np.full((T, 16), np.nan + 0j)
+    Areg = A.copy()
     for q in range(2):
         img[:] = np.nan
         for t in range(T):
+            hi = t >> 8
             for r in range(8):
-                img[512 * r + t] = A[t][8 * q + r]
+                k1 = 8 * (hi ^ q) + r
+                img[512 * r + t] = Areg[t][k1]
+                Areg[t][k1] = np.nan
         for tb in range(T):
-            if (tb >> 8) != q:
-                continue
-            k1, p, b = tb >> 5, (tb >> 4) & 1, tb & 15
-            for a in range(16):
+            k1, p, b, hi = tb >> 5, (tb >> 4) & 1, tb & 15, tb >> 8
+            for aa in range(8):
+                a = 8 * (hi ^ q) + aa
                 b_in[tb][brev4(a)] = img[512 * (k1 & 7) + 32 * a + 2 * b + p]
+    assert np.isnan(Areg).all() and not np.isnan(b_in).any()
     # ---- pass B: FFT16 over a, twiddle W_256^(b k2)
     Bv = np.zeros((T, 16), complex)
     for tb in range(T):
