@@ -46,12 +46,68 @@ __device__ __forceinline__ v2f mv_v(const v2f c0, const v2f c1, const v2f v, con
     return r;
 }
 
+// z += c0 * v.x + c1 * v.y in place (no copy of the result through a control-flow merge)
+__device__ __forceinline__ void mv_acc_s(v2f &z, const v2f c0, const v2f c1, const v2f v)
+{
+    asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(z) : "s"(c0), "s"(c1), "v"(v));
+}
+
 // z <- z + P * shifted(z): one Kogge-Stone level of the affine scan inside a 16-lane row (two DPP moves, two packed FMAs)
 template <int N>
 __device__ __forceinline__ void scan_level8(v2f &z, const float (&p)[4])
 {
     const v2f u = {row_shr<N>(z.x), row_shr<N>(z.y)};
-    z = mv_s(v2f{p[0], p[1]}, v2f{p[2], p[3]}, u, z);
+    mv_acc_s(z, v2f{p[0], p[1]}, v2f{p[2], p[3]}, u);
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Eight 8-byte / sixteen 4-byte LDS reads at compile-time strides AND the wait for them in one asm statement: the outputs are
+// valid when the statement ends.  (Reads left to the compiler are merged into two-element reads whose halves are then
+// copied to their places; reads in separate asm statements may have their outputs copied before the data has arrived.)
+template <int STRIDE>
+__device__ __forceinline__ void lds_read8_b64(cf &r0, cf &r1, cf &r2, cf &r3, cf &r4, cf &r5, cf &r6, cf &r7, unsigned addr)
+{
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:%9\n\tds_read_b64 %2, %8 offset:%10\n\t"
+                 "ds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12\n\tds_read_b64 %5, %8 offset:%13\n\t"
+                 "ds_read_b64 %6, %8 offset:%14\n\tds_read_b64 %7, %8 offset:%15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(addr), "i"(STRIDE), "i"(2 * STRIDE), "i"(3 * STRIDE), "i"(4 * STRIDE), "i"(5 * STRIDE), "i"(6 * STRIDE),
+                   "i"(7 * STRIDE)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_read16_b32(float (&r)[16], unsigned addr)
+{
+    asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:4\n\tds_read_b32 %2, %16 offset:8\n\t"
+                 "ds_read_b32 %3, %16 offset:12\n\tds_read_b32 %4, %16 offset:16\n\tds_read_b32 %5, %16 offset:20\n\t"
+                 "ds_read_b32 %6, %16 offset:24\n\tds_read_b32 %7, %16 offset:28\n\tds_read_b32 %8, %16 offset:32\n\t"
+                 "ds_read_b32 %9, %16 offset:36\n\tds_read_b32 %10, %16 offset:40\n\tds_read_b32 %11, %16 offset:44\n\t"
+                 "ds_read_b32 %12, %16 offset:48\n\tds_read_b32 %13, %16 offset:52\n\tds_read_b32 %14, %16 offset:56\n\t"
+                 "ds_read_b32 %15, %16 offset:60\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+                   "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                 : "v"(addr)
+                 : "memory");
+}
+
+// e + o * u and e + o * conj(u): complex multiply-add as two packed FMAs (broadcast, swap and negation are operand modifiers)
+__device__ __forceinline__ cf cfma(const cf e, const cf o, const cf u)
+{
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                                // e + o.x * (u.x, u.y)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"                       // + o.y * (-u.y, u.x)
+        : "=&v"(r) : "v"(o), "v"(u), "v"(e));
+    return r;
+}
+__device__ __forceinline__ cf cfma_conj(const cf e, const cf o, const cf u)
+{
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"                 // e + o.x * (u.x, -u.y)
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                                      // + o.y * (u.y, u.x)
+        : "=&v"(r) : "v"(o), "v"(u), "v"(e));
+    return r;
 }
 
 // nA += tap * y.x, nB += tap * y.y with tap = (m1, m2) wave-uniform in an aligned scalar pair: the chunk-end states of
@@ -61,6 +117,13 @@ __device__ __forceinline__ void tap8(v2f &nA, v2f &nB, const v2f tap, const v2f 
     asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
         "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
         : "+v"(nA), "+v"(nB) : "s"(tap), "v"(y));
+}
+// the first tap of an accumulator: a product, so that the accumulators are never zeroed
+__device__ __forceinline__ void tap8_first(v2f &nA, v2f &nB, const v2f tap, const v2f y)
+{
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
+        : "=&v"(nA), "=&v"(nB) : "s"(tap), "v"(y));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -80,8 +143,9 @@ __device__ __forceinline__ void stage_in8(const float *__restrict__ xin, const S
     unsigned char *region = smem + wave * 4096;
     const float4 *lds4 = reinterpret_cast<const float4 *>(region);
     float4 raw[8];
+    // defined on every path without an instruction: the lanes of the other sub-round never read what they hold
 #pragma unroll
-    for (int g = 0; g < 8; ++g) raw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(raw[g].x), "=v"(raw[g].y), "=v"(raw[g].z), "=v"(raw[g].w));
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
     float g0 = 0.f;
     if constexpr (WINGEN) {
@@ -92,13 +156,19 @@ __device__ __forceinline__ void stage_in8(const float *__restrict__ xin, const S
     for (int s = 0; s < 2; ++s) {
         if (s == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(3);
+        // slab i = rows 8i .. 8i+7 of the sub-round; the swizzle term of row rr = 8i + (lane >> 3) is ((rr >> 1) & 7) =
+        // (4 i + (lane >> 4)) & 7: slabs i and i + 2 differ by 2048 bytes of source (the instruction's offset field)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rr = 8 * i + (lane >> 3);                       // row inside the sub-round
+        for (int par = 0; par < 2; ++par) {
+            const int rr = 8 * par + (lane >> 3);
             const int lc = (lane & 7) ^ ((rr >> 1) & 7);
             const float *src = xin + (64 * wave + 32 * s + rr) * 32 + lc * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(region + i * 1024), 16, 0, SA_DMA_AUX);
+                                             (__attribute__((address_space(3))) void *)(region + par * 1024), 16, 0, SA_DMA_AUX);
+            // (the instruction's offset field moves the source AND the LDS destination: slab par + 2 = slab par + 2048 bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(region + par * 1024), 16, 2048,
+                                             SA_DMA_AUX);
         }
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -132,9 +202,10 @@ __device__ __forceinline__ void stage_in8(const float *__restrict__ xin, const S
                 const float4 q = wt[e >> 1];
                 w = (e & 1) ? v2f{q.z, q.w} : v2f{q.x, q.y};
             }
-            // one plain multiply per half, straight into its place in the pair (VGPR-only operands: the fast class)
-            d[j].x = xa[e] * w.x;
-            d[j].y = xb[e] * w.y;
+            // one plain multiply per half, straight into its place in the pair (VGPR-only operands: the fast class).
+            // Left to the SLP vectoriser this becomes a packed multiply on pairs assembled with two copies each.
+            asm("v_mul_f32 %0, %1, %2" : "=v"(d[j].x) : "v"(xa[e]), "v"(w.x));
+            asm("v_mul_f32 %0, %1, %2" : "=v"(d[j].y) : "v"(xb[e]), "v"(w.y));
         }
     }
 }
@@ -226,14 +297,11 @@ __device__ __forceinline__ void iir_section8(v2f (&d)[16], const SecT &k, const 
     }
     if constexpr (PREDICT_NEXT) {
         cn = load_sec8(knext);
-        v2f nA0 = {0.f, 0.f}, nB0 = {0.f, 0.f}, nA1 = {0.f, 0.f}, nB1 = {0.f, 0.f};
+        // one accumulator pair per chunk: with eight waves on the SIMD the other waves cover the dependent FMAs, and
+        // a second pair costs four registers of the 64
+        tap8_first(zA, zB, tp[0], d[0]);
 #pragma unroll
-        for (int j = 0; j < SA8_CHUNK; j += 2) {
-            tap8(nA0, nB0, tp[j], d[j]);
-            tap8(nA1, nB1, tp[j + 1], d[j + 1]);
-        }
-        zA = nA0 + nA1;
-        zB = nB0 + nB1;
+        for (int j = 1; j < SA8_CHUNK; ++j) tap8(zA, zB, tp[j], d[j]);
     }
 }
 
@@ -254,30 +322,11 @@ template <int NSEC, bool UNIT, typename PlanT>
 __device__ __forceinline__ void iir_cascade8(v2f (&d)[16], const PlanT &ka, const SaIirLaneTab8 *__restrict__ lt, float2 *scr, int t)
 {
     const Sec8 c0 = load_sec8(ka.sec[0]);
-    v2f nA0 = {0.f, 0.f}, nB0 = {0.f, 0.f}, nA1 = {0.f, 0.f}, nB1 = {0.f, 0.f};
+    v2f zA, zB;
+    tap8_first(zA, zB, v2f{ka.m0[0][0], ka.m0[0][1]}, d[0]);
 #pragma unroll
-    for (int j = 0; j < SA8_CHUNK; j += 2) {
-        tap8(nA0, nB0, v2f{ka.m0[j][0], ka.m0[j][1]}, d[j]);
-        tap8(nA1, nB1, v2f{ka.m0[j + 1][0], ka.m0[j + 1][1]}, d[j + 1]);
-    }
-    v2f zA = nA0 + nA1, zB = nB0 + nB1;
+    for (int j = 1; j < SA8_CHUNK; ++j) tap8(zA, zB, v2f{ka.m0[j][0], ka.m0[j][1]}, d[j]);
     iir_sections8<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, zA, zB, c0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Position of the (E, O) pair of bin kk (compacted, 0 .. 2047) in the natural-order image: 16-byte pairs, two slots of
-// padding per 32 so that the writers (lanes 32 slots apart) and the 16-byte readers (lanes 8 slots apart) are conflict-free.
-__device__ __forceinline__ int slot8(int kk, int p)
-{
-    const int s = 2 * kk + p;
-    return s + 2 * (s >> 5);
-}
-// compacted bin of k (0 .. 4095) in round r: round 0 holds k3 = k >> 8 in {0..3, 12..15}, round 1 {4..11}
-__device__ __forceinline__ int compact8(int k, int r)
-{
-    const int k3 = k >> 8;
-    const int dd = r == 0 ? (k3 & 7) : k3 - 4;          // round 0: 0..3 -> 0..3, 12..15 -> 4..7
-    return (k & 255) + 256 * dd;
 }
 
 template <int NSEC, bool UNIT, int OUT, bool WINGEN>
@@ -341,9 +390,9 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     // ---- pass A: 16-point FFT over m1 (stride 512), then twiddle W_4096^(k1 u), u = t >> 1, from six per-thread
     //      anchors W^(b u), b = 1..3, and W^(4 a u), a = 1..3 (one or two complex products per point)
     SA_STAMP(3);
-    float4 an[4];
+    float4 an[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) an[i] = twT8[i * kT8 + t];
+    for (int i = 0; i < 3; ++i) an[i] = twT8[i * kT8 + t];
     safft::fft_dit<16>(a);
     {
         const cf wb[4] = {{1.f, 0.f}, {an[0].x, an[0].y}, {an[0].z, an[0].w}, {an[1].x, an[1].y}};
@@ -354,8 +403,6 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
             if ((k1 >> 2) != 0) a[k1] = safft::cmul(a[k1], wa[k1 >> 2]);
         }
     }
-    // split-step anchors: W_16384^(4g + 4096 half) and the next group's (chain_f32.hip: bit-identical mirrored halves)
-    const cf wP = {an[3].x, an[3].y}, wPn = {an[3].z, an[3].w};
     SA_STAMP(4);
     // ---- exchange A -> B in two rounds.  The pass-B thread tb = 32 k1 + 16 p + b needs A'[k1][u = 16 a + b], a = 0..15, of its
     //      sub-FFT p, from the writers 2u + p = 32 a + 2 b + p.  Registers and LDS hold the data exactly once, so every thread
@@ -367,26 +414,34 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     {
         cf bq[16];
         const bool hi = __builtin_amdgcn_readfirstlane(t >> 8) != 0;
-        const int base = 512 * (k1B & 7) + 2 * lo + pB;
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem);
+        const unsigned wr = lbase + 8u * (unsigned)t;                                            // + 4096 per row
+        const unsigned rdb = lbase + 8u * (unsigned)(512 * (k1B & 7) + 2 * lo + pB);             // + 256 per a
+        // LDS accesses written out: left to the compiler, the two arms' stores are sunk into one sequence behind sixteen
+        // register copies (and the copies spill)
+#define SA8_WR(SLOT, ROW) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(a[SLOT]), "i"(4096 * (ROW)) : "memory")
+#define SA8_RD(A0) lds_read8_b64<256>(bq[safft::brev((A0), 4)], bq[safft::brev((A0) + 1, 4)], bq[safft::brev((A0) + 2, 4)], \
+                                 bq[safft::brev((A0) + 3, 4)], bq[safft::brev((A0) + 4, 4)], bq[safft::brev((A0) + 5, 4)], \
+                                 bq[safft::brev((A0) + 6, 4)], bq[safft::brev((A0) + 7, 4)], rdb + 256u * (A0))
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             lds_barrier();
             if (hi) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) ldc[512 * r + t] = a[8 * (1 ^ q) + r];
+                for (int r = 0; r < 8; ++r) SA8_WR(8 * (1 ^ q) + r, r);
             } else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) ldc[512 * r + t] = a[8 * q + r];
+                for (int r = 0; r < 8; ++r) SA8_WR(8 * q + r, r);
             }
             lds_barrier();
             if (hi) {
-#pragma unroll
-                for (int aa = 0; aa < 8; ++aa) bq[safft::brev(8 * (1 ^ q) + aa, 4)] = ldc[base + 32 * (8 * (1 ^ q) + aa)];
+                SA8_RD(8 * (1 ^ q));
             } else {
-#pragma unroll
-                for (int aa = 0; aa < 8; ++aa) bq[safft::brev(8 * q + aa, 4)] = ldc[base + 32 * (8 * q + aa)];
+                SA8_RD(8 * q);
             }
         }
+#undef SA8_WR
+#undef SA8_RD
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = bq[i];
     }
@@ -406,15 +461,18 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     //      exchange is still being read by the other half of the workgroup).
     lds_barrier();            // the other half of the workgroup may still be reading the image of round 1
     {
+        // plane 0: the real parts leave, the transposed ones come back as sixteen single registers; plane 1: the same for
+        // the imaginary parts; then (re, im) pairs.  Single-dword reads in one asm statement each: the register allocator
+        // places re[b], im[b] side by side and no value is copied.
         float *gb = ldf + (t >> 4) * 272;
+        const unsigned rd = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(gb + lo * 17);
+        float re[16], im[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) gb[c * 17 + lo] = a[c].x;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float re[16];
-#pragma unroll
-        for (int b = 0; b < 16; ++b) re[b] = gb[lo * 17 + b];
+        lds_read16_b32(re, rd);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -423,8 +481,9 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lds_read16_b32(im, rd);
 #pragma unroll
-        for (int b = 0; b < 16; ++b) a[safft::brev(b, 4)] = cf{re[b], gb[lo * 17 + b]};
+        for (int b = 0; b < 16; ++b) a[safft::brev(b, 4)] = cf{re[b], im[b]};
     }
     SA_STAMP(7);
     // ---- pass C: 16-point FFT over b -> k3;  F_p[k1 + 16 k2 + 256 k3], k2 = lo
@@ -433,73 +492,93 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     // ---- natural-order image of (E, O) pairs + output stage, two rounds: round 0 = k3 in {0..3, 12..15} (bins k < 1024 and
     //      their partners 4096 - k), round 1 = k3 in {4..11}.  Bin 1024 (needed by round 0's last group) and bin 3072 (its
     //      partner in round 1) are not in that round's image and travel through four side slots.
+    // The thread's group: bins kappa0 .. kappa0+3 (+ one for the mirrored streams), kappa0 = 4g + 1024 r + 4096 half.  It reads
+    // E, O at k = kappa mod 4096 and at 4096 - k and forms the two Z of its pair with its OWN twiddle squared:
+    //   u = W_16384^(2 kappa):  Z[kappa] = E[k] + u O[k],  Z[8192 - kappa] = E[4096-k] + conj(u) O[4096-k]
+    // (for half = 1 that is E - W_8192^k O and E' - conj(W_8192^k) O': the same code).
+    // Where the group's pairs sit in the image does not depend on the round (compacted bin of k0 = 4g is 4g in both, of
+    // 4096 - k0 - 4 it is 4 (511 - g)): four byte addresses, computed once -- run of four pairs at k0, the pair at k0 + 4,
+    // run of four at 4096 - k0 - 4 .. 4096 - k0 - 1, the pair at 4096 - k0.
+    // split-step anchors: W_16384^(4g + 4096 half) and the next group's (chain_f32.hip: bit-identical mirrored halves)
+    const float4 an3 = twT8[3 * kT8 + t];
+    const cf wP = {an3.x, an3.y}, wPn = {an3.z, an3.w};
+    const int g = t >> 1, half = t & 1;
+    const int g1 = g + 1, gm = 511 - g, gz = 512 - g;
+    const int A1 = 64 * g + 16 * (g >> 2), A2 = 64 * g1 + 16 * (g1 >> 2), A3 = 64 * gm + 16 * (gm >> 2);
+    const int A4 = 64 * gz + 16 * (gz >> 2);
+    const int wimg = 8 * (2 * k1B + 32 * lo + pB + 2 * ((2 * k1B + 32 * lo + pB) >> 5));      // writer: + 4352 bytes per dd
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         lds_barrier();
 #pragma unroll
         for (int dd = 0; dd < 8; ++dd) {
             const int k3 = (r == 0) ? (dd < 4 ? dd : dd + 8) : dd + 4;
-            ldc[slot8(k1B + 16 * lo + 256 * dd, pB)] = a[k3];
+            *reinterpret_cast<cf *>(smem + wimg + 4352 * dd) = a[k3];
         }
         if (k1B == 0 && lo == 0) side[2 * r + pB] = a[r == 0 ? 4 : 12];       // bin 1024 (round 0) / 3072 (round 1)
         lds_barrier();
         SA_STAMP(9 + r);
-        // the thread's group: bins kappa0 .. kappa0+3 (+ one for the mirrored streams), kappa0 = 4g + 1024 r + 4096 half.
-        // It reads E, O at k = kappa mod 4096 and at 4096 - k and forms the two Z of its pair with its OWN twiddle squared:
-        //   u = W_16384^(2 kappa):  Z[kappa] = E[k] + u O[k],  Z[8192 - kappa] = E[4096-k] + conj(u) O[4096-k]
-        // (for half = 1 that is E - W_8192^k O and E' - conj(W_8192^k) O': the same code).
-        const int g = t >> 1, half = t & 1;
         const int k0 = 4 * g + 1024 * r;
-        cf w[5];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = cmul_s(wP, twC[r * 5 + e]);
-        {
-            const float2 c0 = twC[r * 5], c1 = twC[(r + 1) * 5];
-            const cf csel = (g == 255) ? cf{c1.x, c1.y} : cf{c0.x, c0.y};
-            w[4] = safft::cmul(wPn, csel);
-        }
+        // round 0: bin 1024 (g = 255, e = 4) comes from the side slots, the partner of bin 0 is bin 0;
+        // round 1: the partner of bin 1024 (g = 0, e = 0) is bin 3072: side slots
+        const int A2r = (r == 0 && g == 255) ? kSide8 : A2;
+        const int A4r = (g == 0) ? (r == 0 ? 0 : kSide8 + 16) : A4;
         cf R[5], I[5];
+        float mp[5], mq[5];
 #pragma unroll
         for (int e = 0; e < 5; ++e) {
-            const int k = k0 + e, kp = (4096 - k) & 4095;
-            float4 eo, eop;
-            if (e == 4 && r == 0) {
-                // bin 1024 sits in round 1's image: side slots
-                const int sk = slot8(compact8(k & 1023, 0), 0);                 // any valid address for the other lanes
-                eo = *reinterpret_cast<const float4 *>(&ldc[sk]);
-                if (g == 255) eo = *reinterpret_cast<const float4 *>(&side[0]);
+            const v4f eo = *reinterpret_cast<const v4f *>(smem + (e < 4 ? A1 + 16 * e : A2r));
+            const v4f eop = *reinterpret_cast<const v4f *>(smem + (e == 0 ? A4r : A3 + 16 * (4 - e)));
+            cf w;
+            if (e < 4) {
+                w = cmul_s(wP, twC[r * 5 + e]);
             } else {
-                eo = *reinterpret_cast<const float4 *>(&ldc[slot8(compact8(k, r), 0)]);
+                // bin kappa0 + 4 is bin 0 of the neighbouring group, which also stores it: the mirrored halves of the
+                // spectrum stay bit-identical only if both evaluate the same product (chain_f32.hip)
+                const float2 c0 = twC[r * 5], c1 = twC[(r + 1) * 5];
+                const cf csel = (g == 255) ? cf{c1.x, c1.y} : cf{c0.x, c0.y};
+                w = safft::cmul(wPn, csel);
             }
-            if (e == 0 && r == 1) {
-                // partner of bin 1024 is bin 3072, which sits in round 0's image: side slots
-                const int sk = slot8(compact8(kp == 3072 ? 3071 : kp, 1), 0);
-                eop = *reinterpret_cast<const float4 *>(&ldc[sk]);
-                if (g == 0) eop = *reinterpret_cast<const float4 *>(&side[2]);
-            } else {
-                eop = *reinterpret_cast<const float4 *>(&ldc[slot8(compact8(kp, r), 0)]);
-            }
-            const cf u = safft::cmul(w[e], w[e]);
-            const cf zk = cf{eo.x, eo.y} + safft::cmul(cf{eo.z, eo.w}, u);
-            const cf uc = {u.x, -u.y};
-            const cf zm = cf{eop.x, eop.y} + safft::cmul(cf{eop.z, eop.w}, uc);
-            split_eval(zk, zm, w[e], R[e], I[e]);
-        }
-        if constexpr (OUT == SA_OUT_MAG_FULL) {
-            // bins 2048 / 14336 and 6144 / 10240 are written by the two halves of the last group from the two sides of the
-            // SAME pair (P of one half, Q of the other): equal in exact arithmetic; to keep the mirrored halves of the
-            // spectrum bit-identical the odd lane takes its Q from the even lane's P and gives its P for the even lane's Q
-            if (r == 1 && (t >> 6) == 7) {
-                const float pr = R[4].x, pi = I[4].x;
-                const float nr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pr), 0xB1, 0xF, 0xF, true));
-                const float ni = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pi), 0xB1, 0xF, 0xF, true));
-                if (g == 255) {
-                    R[4].y = nr;
-                    I[4].y = ni;
+            const cf u = safft::cmul(w, w);
+            const cf zk = cfma(cf{eo.x, eo.y}, cf{eo.z, eo.w}, u);
+            const cf zm = cfma_conj(cf{eop.x, eop.y}, cf{eop.z, eop.w}, u);
+            split_eval(zk, zm, w, R[e], I[e]);
+            if constexpr (OUT == SA_OUT_MAG_FULL) {
+                // bins 2048 / 14336 and 6144 / 10240 are written by the two halves of the last group from the two sides of
+                // the SAME pair (P of one half, Q of the other): equal in exact arithmetic; to keep the mirrored halves of
+                // the spectrum bit-identical both lanes take their Q from the neighbouring lane's P
+                if (e == 4 && r == 1 && (t >> 6) == 7) {
+                    const float nr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R[4].x), 0xB1, 0xF, 0xF, true));
+                    const float ni = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, I[4].x), 0xB1, 0xF, 0xF, true));
+                    if (g == 255) {
+                        R[4].y = nr;
+                        I[4].y = ni;
+                    }
                 }
             }
+            if constexpr (OUT != SA_OUT_SPEC_HALF) {
+                const cf m2 = safft::pk_fma(I[e], I[e], R[e] * R[e]);          // (|P|^2, |Q|^2)
+                mp[e] = fast_sqrt(m2.x);
+                mq[e] = fast_sqrt(m2.y);
+            }
         }
-        split_store<OUT>(R, I, out, f, k0 + 4096 * half);
+        const int kap0 = k0 + 4096 * half;
+        if constexpr (OUT == SA_OUT_MAG_FULL) {
+            float *o = reinterpret_cast<float *>(out) + (size_t)f * SA_NPTS;
+            store_nt(o + kap0, mp[0], mp[1], mp[2], mp[3]);
+            store_nt(o + SA_NPTS - kap0 - 4, mp[4], mp[3], mp[2], mp[1]);
+            store_nt(o + SA_MC + kap0, mq[0], mq[1], mq[2], mq[3]);
+            store_nt(o + SA_MC - kap0 - 4, mq[4], mq[3], mq[2], mq[1]);
+        } else if constexpr (OUT == SA_OUT_MAG_HALF) {
+            float *o = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);     // rows are not 16-byte aligned
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_nt(o + kap0 + e, mp[e]);
+#pragma unroll
+            for (int e = 1; e < 5; ++e) store_nt(o + SA_MC - kap0 - e, mq[e]);
+            if (kap0 == 0) store_nt(o + SA_MC, mq[0]);
+        } else {
+            split_store<OUT>(R, I, out, f, kap0);
+        }
     }
     SA_STAMP(11);
 }
