@@ -1,8 +1,15 @@
-// chain_f32_w8.hip -- the fused float signal path at EIGHT waves per SIMD (gfx950, MI355X):
+// probes/chain_f32_w8.hip -- the fused float signal path at EIGHT waves per SIMD (gfx950, MI355X):
 //     Hann window -> 6-section biquad cascade -> 16384-point real FFT -> magnitude / half spectrum
 // (new/hann8192.vhd -> new/filter_iir12_cust.vhd -> ip/xfft_0 of the reference), one 512-thread workgroup per frame,
-// <= 64 VGPRs and 36 KiB of LDS so that four workgroups = 32 waves share a CU.  chain_f32.hip keeps the 256-thread
-// form (4 waves per SIMD) for the IIR-bypassed path and the time-series output.
+// <= 64 VGPRs and 39 KiB of LDS so that four workgroups = 32 waves share a CU.
+//
+// NOT PART OF THE PRODUCT LIBRARY.  Round 3 built this form (the round-2 review's first item), got it bit-for-bit
+// through the whole float GPU suite and measured it: 150-160 us per 4096 frames against 131-134 us for the 256-thread
+// kernel of chain_f32.hip on the same box (profiles/r3_w8_vs_w4.txt: A/B runs and counters).  Twice the waves of the SAME
+// four workgroups per CU add no independent phases to a SIMD -- the waves of a workgroup wait at the same barriers
+// together -- while every barrier now gathers eight waves, the exchanges need 66 % more LDS instructions and the
+// 64-register budget leaves spills.  It is compiled only into A/B builds (make ab NAME=w8 W8=1 in csrc/), where the
+// handle then launches it for the IIR modes; tools/w8_model.py and tools/w8_debug.py belong to it.
 //
 // Same algorithm as chain_f32.hip (predict / scan / recurse per section, FFT in registers, split step), other partition:
 //   * thread t owns samples [32t, 32t+32) as two consecutive chunks of 16, held as float pairs (chunk A in .x, chunk B
@@ -17,15 +24,21 @@
 //   * LDS holds half a frame (as in chain_f32.hip); the 16x16 transposes between the last two passes go through LDS one
 //     float plane at a time so that all 32 sixteen-lane groups have room at once (no workgroup barrier there).
 // tools/w8_model.py is the index model of everything below (checked against numpy.fft on the CPU).
-#include "chain_f32_dev.hpp"
+#include "../chain_f32_dev.hpp"
 
 namespace {
 
+#ifndef SA8_WAVES_PER_SIMD
+#define SA8_WAVES_PER_SIMD 8          // launch bound (A/B builds: 6 = three workgroups per CU at 80 VGPRs)
+#endif
 constexpr int kT8 = SA8_NTHREADS;
 constexpr int kImg8 = 4352;                       // complex slots of the exchange image (34 KiB)
 constexpr int kScr8 = kImg8 * 8;                  // scan scratch: 6 sections x 32 rows x float2
 constexpr int kSide8 = kScr8 + 6 * SA8_ROWS * 8;  // four complex side slots: E, O at bin 1024 (round 0) / 3072 (round 1)
-constexpr int kLds8 = kSide8 + 32;
+constexpr int kLane8 = kSide8 + 32;               // the per-lane matrices P2^i of the six sections (SaIirLaneTab8::p), 1.5 KiB:
+                                                  // read per section with a 32-bit LDS address instead of a 64-bit global one
+constexpr int kTwB8 = kLane8 + SA_MAXSEC * 16 * 16; // the pass-B twiddles (SaF32Tables::twB, 2 KiB): LDS latency needs no early loads
+constexpr int kLds8 = kTwB8 + 8 * 16 * 16;          // 39 968 B: four workgroups per CU (40 KiB each)
 
 // r = add + c0 * v.x + c1 * v.y : a 2x2 matrix (columns c0, c1) times v, plus add.  _s: wave-uniform columns in scalar
 // register pairs; _v: per-lane columns.  One asm statement each (no compiler pad between the dependent FMAs).
@@ -229,7 +242,7 @@ __device__ __forceinline__ Sec8 load_sec8(const SecT &k)
 //   zA, zB (out): the same for the NEXT section (accumulated over this section's outputs)
 template <bool PREDICT_NEXT, bool UNIT, typename SecT>
 __device__ __forceinline__ void iir_section8(v2f (&d)[16], const SecT &k, const SecT &knext, const Sec8 c, Sec8 &cn,
-                                             const float4 lanep, float2 *scr_s, int lane, int wave, v2f &zA, v2f &zB)
+                                             const float4 *lanetab_lds, float2 *scr_s, int lane, int wave, v2f &zA, v2f &zB)
 {
     // state after both chunks of this thread, from zero state: T = Pc zA + zB
     v2f T = mv_s(c.pc0, c.pc1, zA, zB);
@@ -243,6 +256,7 @@ __device__ __forceinline__ void iir_section8(v2f (&d)[16], const SecT &k, const 
     if ((lane & 15) == 15) scr_s[row] = make_float2(T.x, T.y);
     const v2f e = {row_shr<1>(T.x), row_shr<1>(T.y)};            // exclusive: state before this thread, row-local
     lds_barrier();
+    const float4 lanep = lanetab_lds[lane & 15];                 // P2^i (in LDS since the kernel's first instructions)
     v2f cst;
     if (flags & SA_IIR_SKIP_ROWSCAN) {
         // a row (512 samples) outlasts the section's memory: the row starts from the previous row's total
@@ -273,12 +287,6 @@ __device__ __forceinline__ void iir_section8(v2f (&d)[16], const SecT &k, const 
     // pole coordinates -> DF2T states of the recursion, re-paired as (chunk A, chunk B)
     const v2f q1 = {aS.x, bS.x}, q2 = {aS.y, bS.y};
     v2f s1 = c.mb0.x * q1 + c.mb1.x * q2, s2 = c.mb0.y * q1 + c.mb1.y * q2;
-    // the next section's tap pairs: requested now, consumed after the recursion
-    v2f tp[SA8_CHUNK];
-    if constexpr (PREDICT_NEXT) {
-#pragma unroll
-        for (int j = 0; j < SA8_CHUNK; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
-    }
     const float b0 = c.b0, b1 = c.b1, b2 = c.b2, na1 = -c.a1, na2 = -c.a2;
 #pragma unroll
     for (int j = 0; j < SA8_CHUNK; ++j) {
@@ -296,6 +304,13 @@ __device__ __forceinline__ void iir_section8(v2f (&d)[16], const SecT &k, const 
         d[j] = y;
     }
     if constexpr (PREDICT_NEXT) {
+        // the next section's tap pairs and constants: requested here, behind the recursion -- eight waves per SIMD cover the
+        // scalar-load latency, and 32 + 14 scalar registers less are live across the recursion (the kernel must stay within
+        // 80 SGPRs for eight waves per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
+        v2f tp[SA8_CHUNK];
+#pragma unroll
+        for (int j = 0; j < SA8_CHUNK; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
         cn = load_sec8(knext);
         // one accumulator pair per chunk: with eight waves on the SIMD the other waves cover the dependent FMAs, and
         // a second pair costs four registers of the 64
@@ -310,7 +325,7 @@ __device__ __forceinline__ void iir_sections8(v2f (&d)[16], const PlanT &ka, con
                                               int lane, int wave, v2f &zA, v2f &zB, const Sec8 c)
 {
     if constexpr (S < NSEC) {
-        const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
+        const float4 *lanep = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(scr) - kScr8 + kLane8) + S * 16;
         Sec8 cn = c;
         iir_section8<(S + 1 < NSEC), UNIT>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + SA8_ROWS * S, lane,
                                            wave, zA, zB);
@@ -330,7 +345,7 @@ __device__ __forceinline__ void iir_cascade8(v2f (&d)[16], const PlanT &ka, cons
 }
 
 template <int NSEC, bool UNIT, int OUT, bool WINGEN>
-__global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__restrict__ in, void *__restrict__ out, int batch,
+__global__ __launch_bounds__(kT8, SA8_WAVES_PER_SIMD) void chain_f32_w8_kernel(const float *__restrict__ in, void *__restrict__ out, int batch,
                                                               const float4 *__restrict__ twT8, const float4 *__restrict__ twB,
                                                               const float2 *__restrict__ twC,
                                                               const SaIirLaneTab8 *__restrict__ lanetab, const SaIirK8 ka)
@@ -347,6 +362,9 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     cf a[16];
     SA_STAMP(0);
     {
+        // the lane matrices of the plan go to LDS (first read behind the first scan barrier)
+        if (t < NSEC * 16) reinterpret_cast<float4 *>(smem + kLane8)[t] = reinterpret_cast<const float4 *>(lanetab->p)[t];
+        if (t >= 128 && t < 256) reinterpret_cast<float4 *>(smem + kTwB8)[t - 128] = twB[t - 128];
         v2f d[16];
         stage_in8<WINGEN>(xin, lanetab, smem, t, d);
         SA_STAMP(1);
@@ -423,22 +441,30 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
 #define SA8_RD(A0) lds_read8_b64<256>(bq[safft::brev((A0), 4)], bq[safft::brev((A0) + 1, 4)], bq[safft::brev((A0) + 2, 4)], \
                                  bq[safft::brev((A0) + 3, 4)], bq[safft::brev((A0) + 4, 4)], bq[safft::brev((A0) + 5, 4)], \
                                  bq[safft::brev((A0) + 6, 4)], bq[safft::brev((A0) + 7, 4)], rdb + 256u * (A0))
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        // each half runs BOTH rounds inside its own arm (every wave meets the same four barriers): merged after each
+        // round, all sixteen registers of bq would count as live from the first round on
+        if (hi) {
             lds_barrier();
-            if (hi) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) SA8_WR(8 * (1 ^ q) + r, r);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) SA8_WR(8 * q + r, r);
-            }
+            for (int r = 0; r < 8; ++r) SA8_WR(8 + r, r);
             lds_barrier();
-            if (hi) {
-                SA8_RD(8 * (1 ^ q));
-            } else {
-                SA8_RD(8 * q);
-            }
+            SA8_RD(8);
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) SA8_WR(r, r);
+            lds_barrier();
+            SA8_RD(0);
+        } else {
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) SA8_WR(r, r);
+            lds_barrier();
+            SA8_RD(0);
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) SA8_WR(8 + r, r);
+            lds_barrier();
+            SA8_RD(8);
         }
 #undef SA8_WR
 #undef SA8_RD
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     safft::fft_dit<16>(a);
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {                       // twB[pp][b] = (W_256^(2pp * b), W_256^((2pp+1) * b))
-        const float4 w = twB[pp * 16 + lo];
+        const float4 w = reinterpret_cast<const float4 *>(smem + kTwB8)[pp * 16 + lo];
         if (pp > 0) a[2 * pp] = safft::cmul(a[2 * pp], {w.x, w.y});
         a[2 * pp + 1] = safft::cmul(a[2 * pp + 1], {w.z, w.w});
     }
@@ -500,13 +526,18 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
     // 4096 - k0 - 4 it is 4 (511 - g)): four byte addresses, computed once -- run of four pairs at k0, the pair at k0 + 4,
     // run of four at 4096 - k0 - 4 .. 4096 - k0 - 1, the pair at 4096 - k0.
     // split-step anchors: W_16384^(4g + 4096 half) and the next group's (chain_f32.hip: bit-identical mirrored halves)
-    const float4 an3 = twT8[3 * kT8 + t];
+    // (an opaque copy of the thread index: everything the output stage derives from it -- the anchor load, five LDS
+    //  addresses -- is computed here and not hoisted to the top of the kernel, kept across it and spilled)
+    int to = t;
+    asm volatile("" : "+v"(to));
+    const float4 an3 = twT8[3 * kT8 + to];
     const cf wP = {an3.x, an3.y}, wPn = {an3.z, an3.w};
-    const int g = t >> 1, half = t & 1;
+    const int g = to >> 1, half = to & 1;
     const int g1 = g + 1, gm = 511 - g, gz = 512 - g;
     const int A1 = 64 * g + 16 * (g >> 2), A2 = 64 * g1 + 16 * (g1 >> 2), A3 = 64 * gm + 16 * (gm >> 2);
     const int A4 = 64 * gz + 16 * (gz >> 2);
-    const int wimg = 8 * (2 * k1B + 32 * lo + pB + 2 * ((2 * k1B + 32 * lo + pB) >> 5));      // writer: + 4352 bytes per dd
+    const int k1o = to >> 5, po = (to >> 4) & 1, loo = to & 15;
+    const int wimg = 8 * (2 * k1o + 32 * loo + po + 2 * ((2 * k1o + 32 * loo + po) >> 5));      // writer: + 4352 bytes per dd
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         lds_barrier();
@@ -515,7 +546,7 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
             const int k3 = (r == 0) ? (dd < 4 ? dd : dd + 8) : dd + 4;
             *reinterpret_cast<cf *>(smem + wimg + 4352 * dd) = a[k3];
         }
-        if (k1B == 0 && lo == 0) side[2 * r + pB] = a[r == 0 ? 4 : 12];       // bin 1024 (round 0) / 3072 (round 1)
+        if (k1o == 0 && loo == 0) side[2 * r + po] = a[r == 0 ? 4 : 12];       // bin 1024 (round 0) / 3072 (round 1)
         lds_barrier();
         SA_STAMP(9 + r);
         const int k0 = 4 * g + 1024 * r;
@@ -547,7 +578,7 @@ __global__ __launch_bounds__(kT8, 8) void chain_f32_w8_kernel(const float *__res
                 // bins 2048 / 14336 and 6144 / 10240 are written by the two halves of the last group from the two sides of
                 // the SAME pair (P of one half, Q of the other): equal in exact arithmetic; to keep the mirrored halves of
                 // the spectrum bit-identical both lanes take their Q from the neighbouring lane's P
-                if (e == 4 && r == 1 && (t >> 6) == 7) {
+                if (e == 4 && r == 1 && (to >> 6) == 7) {
                     const float nr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R[4].x), 0xB1, 0xF, 0xF, true));
                     const float ni = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, I[4].x), 0xB1, 0xF, 0xF, true));
                     if (g == 255) {

@@ -116,6 +116,7 @@ inline void put_cm(float *dst, const Mat2 &m)      // column-major
     dst[0] = (float)m.a; dst[1] = (float)m.c; dst[2] = (float)m.b; dst[3] = (float)m.d;
 }
 
+#ifdef SA_WITH_W8      // A/B builds with the 512-thread probe kernel (probes/chain_f32_w8.hip) only
 // The plan of the 512-thread kernels (SaIirK8 / SaIirLaneTab8 in sa_common.hpp): same algebra as build_plan below
 // with 16-sample chunks, 32-sample threads, 512-sample rows, matrices column-major.
 void build_plan8(const double *sos_in, int nsec_in, SaIirK8 *plan, SaIirLaneTab8 *lt, const float *half_win,
@@ -198,6 +199,7 @@ void build_plan8(const double *sos_in, int nsec_in, SaIirK8 *plan, SaIirLaneTab8
         }
     }
 }
+#endif
 
 // Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
 // The kernels are compiled for 2, 4 and 6 sections; shorter cascades are padded with identity
@@ -328,8 +330,10 @@ struct sa_handle {
     std::vector<int16_t> rom;
     SaIirK plan_default{}, plan_custom{};
     SaIirLaneTab lt_default{}, lt_custom{};
-    SaIirK8 plan8_default{}, plan8_custom{};          // the same cascades in the 512-thread kernels' layout
+#ifdef SA_WITH_W8
+    SaIirK8 plan8_default{}, plan8_custom{};          // the same cascades in the 512-thread probe kernels' layout
     SaIirLaneTab8 lt8_default{}, lt8_custom{};
+#endif
     std::vector<float> half_win;           // 0.5 * float window, natural order
     bool win_is_cos = true;                // the float window is a0 - a1 cos(2 pi n / (N-1)) (default: Hann)
     double win_cos[2] = {0.5, 0.5};
@@ -410,6 +414,7 @@ int fail(sa_handle *h, int code, const char *what, hipError_t e = hipSuccess)
     } while (0)
 
 constexpr size_t kStageBytes = sizeof(SaIirLaneTab8) > sizeof(SaIirLaneTab) ? sizeof(SaIirLaneTab8) : sizeof(SaIirLaneTab);
+// (the probe kernels' table is the larger one; sized for it in every build so that the staging ring does not change)
 static_assert(kStageBytes >= sizeof(float) * SA_NPTS, "a staging slot holds any table of the handle");
 
 // Control-plane calls change host state and device tables; a process call that is being captured into a hipGraph
@@ -664,10 +669,11 @@ int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
     h->nsec_custom = nsec;
     const double *cw = h->win_is_cos ? h->win_cos : nullptr;
     build_plan(h->sos_custom, nsec, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
+#ifdef SA_WITH_W8
     build_plan8(h->sos_custom, nsec, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), cw);
-    const int rc = upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
-    if (rc != SA_OK) return rc;
-    return upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8));
+    { const int rc8 = upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8)); if (rc8 != SA_OK) return rc8; }
+#endif
+    return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
 int rebuild_plans(sa_handle *h)
@@ -676,16 +682,18 @@ int rebuild_plans(sa_handle *h)
     sos_from_q7(kDefaultQ7, sos);
     const double *cw = h->win_is_cos ? h->win_cos : nullptr;
     build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data(), cw);
-    build_plan8(sos, 6, &h->plan8_default, &h->lt8_default, h->half_win.data(), cw);
     int rc = upload(h, h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab));
     if (rc != SA_OK) return rc;
+    build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
+#ifdef SA_WITH_W8
+    build_plan8(sos, 6, &h->plan8_default, &h->lt8_default, h->half_win.data(), cw);
     rc = upload(h, h->d_lt8_default, &h->lt8_default, sizeof(SaIirLaneTab8));
     if (rc != SA_OK) return rc;
-    build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
     build_plan8(h->sos_custom, h->nsec_custom, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), cw);
-    rc = upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
+    rc = upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8));
     if (rc != SA_OK) return rc;
-    return upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8));
+#endif
+    return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
 }  // namespace
@@ -732,9 +740,11 @@ int sa_create(int device, sa_handle **out)
     SA_HIPC(hipMalloc(&h->d_twC, sizeof(float2) * 25));
     SA_HIPC(hipMalloc(&h->d_lt_default, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
+#ifdef SA_WITH_W8
     SA_HIPC(hipMalloc(&h->d_lt8_default, sizeof(SaIirLaneTab8)));
     SA_HIPC(hipMalloc(&h->d_lt8_custom, sizeof(SaIirLaneTab8)));
     SA_HIPC(hipMalloc(&h->d_twT8, sizeof(float4) * 4 * SA8_NTHREADS));
+#endif
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint2) * SA_NPTS));
 
@@ -778,6 +788,7 @@ int sa_create(int device, sa_handle **out)
                 tc[blk * 5 + e] = make_float2((float)std::cos(ang), (float)std::sin(ang));
             }
         SA_HIPC(hipMemcpy(h->d_twT, ta.data(), sizeof(float4) * ta.size(), hipMemcpyHostToDevice));
+#ifdef SA_WITH_W8
         // per-thread anchors of the 512-thread kernels (SaF32Tables::twT8); multiples of a quarter turn are exact
         std::vector<float4> t8(4 * SA8_NTHREADS);
         auto wexact = [](long e, long n) {                  // exp(-2 pi i e / n), e reduced first
@@ -800,6 +811,7 @@ int sa_create(int device, sa_handle **out)
             t8[3 * SA8_NTHREADS + t] = make_float4(a.x, a.y, b.x, b.y);
         }
         SA_HIPC(hipMemcpy(h->d_twT8, t8.data(), sizeof(float4) * t8.size(), hipMemcpyHostToDevice));
+#endif
         SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float4) * tb.size(), hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_twC, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
@@ -809,15 +821,19 @@ int sa_create(int device, sa_handle **out)
         sos_from_q7(kDefaultQ7, sos);
         build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
+#ifdef SA_WITH_W8
         build_plan8(sos, 6, &h->plan8_default, &h->lt8_default, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt8_default, &h->lt8_default, sizeof(SaIirLaneTab8), hipMemcpyHostToDevice));
+#endif
         sos_from_q7(h->c12_custom, sos);
         std::memcpy(h->sos_custom, sos, sizeof sos);
         h->nsec_custom = 6;
         build_plan(sos, 6, &h->plan_custom, &h->lt_custom, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
+#ifdef SA_WITH_W8
         build_plan8(sos, 6, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8), hipMemcpyHostToDevice));
+#endif
     }
     // integer tables
     {
@@ -1189,18 +1205,18 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;
-        t.lanetab8 = h->d_lt8_default;
-        t.iir8 = &h->plan8_default;
     } else if (h->filter_mode == SA_FILTER_CUSTOM) {
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
-        t.lanetab8 = h->d_lt8_custom;
+    }
+    hipError_t le = hipErrorNotSupported;
+#ifdef SA_WITH_W8                          // A/B builds only: the 512-thread probe kernels for the IIR modes with a spectrum output
+    if (h->filter_mode == SA_FILTER_DEFAULT) {
+        t.lanetab8 = h->d_lt8_default;
+        t.iir8 = &h->plan8_default;
+    } else if (h->filter_mode == SA_FILTER_CUSTOM) {
         t.iir8 = &h->plan8_custom;
     }
-    // IIR modes with a spectrum output: the 512-thread kernels (8 waves per SIMD); everything else -- the bypassed path,
-    // the time-series output -- the 256-thread kernels
-    hipError_t le = hipErrorNotSupported;
-#ifndef SA_AB_NO_W8                        // A/B builds only: the 256-thread kernels everywhere
     le = sa_launch_chain_f32_w8(in, out, batch, out_kind, t, c.stream, c.stop);
 #endif
     if (le == hipErrorNotSupported) le = sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, c.stop);
