@@ -29,13 +29,41 @@ constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 section
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
 constexpr int kLdsBytes = kSideOff + 16;              // two complex side slots
 
-// z <- z + P * shifted(z): one Kogge-Stone level of the affine scan inside a row
-template <int N, typename MatT>
-__device__ __forceinline__ void scan_level(float &z1, float &z2, const MatT &p)
+// The two-component scan state travels as ONE register pair and every 2x2 matrix is stored column-major (a column is
+// an aligned register pair): a matrix-vector product is two packed FMAs, column x broadcast component -- for wave-uniform
+// matrices straight from their scalar registers.  (Round 3, tools/ubench/valu_throughput.hip: on gfx950 a plain fp32
+// instruction with a scalar or DPP operand costs what a packed one costs, so four scalar FMAs per product were four
+// packed-instruction slots.)
+//   mv_s / mv_v: r = add + c0 * v.x + c1 * v.y with wave-uniform (SGPR) / per-lane (VGPR) columns;  mv_acc_s: in place
+__device__ __forceinline__ v2f mv_s(const v2f c0, const v2f c1, const v2f v, const v2f add)
 {
-    const float u1 = row_shr<N>(z1), u2 = row_shr<N>(z2);
-    z1 = __builtin_fmaf(p[0], u1, __builtin_fmaf(p[1], u2, z1));
-    z2 = __builtin_fmaf(p[2], u1, __builtin_fmaf(p[3], u2, z2));
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(r) : "s"(c0), "s"(c1), "v"(v), "v"(add));
+    return r;
+}
+__device__ __forceinline__ v2f mv_v(const v2f c0, const v2f c1, const v2f v, const v2f add)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %3, %4 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(r) : "v"(c0), "v"(c1), "v"(v), "v"(add));
+    return r;
+}
+__device__ __forceinline__ void mv_acc_s(v2f &z, const v2f c0, const v2f c1, const v2f v)
+{
+    asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(z) : "s"(c0), "s"(c1), "v"(v));
+}
+
+// z <- z + P * shifted(z): one Kogge-Stone level of the affine scan inside a row (two DPP moves, two packed FMAs)
+template <int N, typename MatT>
+__device__ __forceinline__ void scan_level(v2f &z, const MatT &p)
+{
+    const v2f u = {row_shr<N>(z.x), row_shr<N>(z.y)};
+    mv_acc_s(z, v2f{p[0], p[1]}, v2f{p[2], p[3]}, u);
 }
 
 __device__ __forceinline__ float mul_to(float a, float b)
@@ -104,62 +132,67 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
         __builtin_amdgcn_sched_barrier(0);
         const int sw = (t >> 1) & 7;
-        const float P = h == 0 ? pq.x : pq.z, Q = h == 0 ? pq.y : pq.w;
+        // WINGEN: round 0 evaluates the window of BOTH chunks as pairs (chunk A, chunk B) -- two packed FMAs per pair with
+        // the wave-uniform (c_j, s_j) in a scalar pair -- multiplies chunk A and parks chunk B's factor in the pair's
+        // other half, where round 1 multiplies it in place.  (Per sample it used to be two scalar-operand FMAs, each of
+        // which costs a packed-instruction slot on gfx950: tools/ubench/valu_throughput.hip.)
+        const v2f Pw = {pq.x, pq.z}, Qw = {pq.y, pq.w}, G0 = {g0, g0};
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             // two batches of four units: all eight in flight at once push the kernel over 128 VGPRs
             if (g == 4) __builtin_amdgcn_sched_barrier(0);
             const float4 q = lds4[t * 8 + (g ^ sw)];
-            float4 w;
+            const float qv[4] = {q.x, q.y, q.z, q.w};
             if constexpr (WINGEN) {
-                float wv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    wv[e] = __builtin_fmaf(Q, lt->wcs[4 * g + e][1], __builtin_fmaf(P, lt->wcs[4 * g + e][0], g0));
-                w = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * g + e;
+                    if (h == 0) {
+                        const v2f cs = {lt->wcs[j][0], lt->wcs[j][1]};
+                        v2f w;
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %0, %4, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                            : "=&v"(w) : "v"(Pw), "s"(cs), "v"(G0), "v"(Qw));
+                        d[j].x = mul_to(qv[e], w.x);
+                        d[j].y = w.y;
+                    } else {
+                        d[j].y = mul_to(qv[e], d[j].y);
+                    }
+                }
             } else {
-                w = wint[(8 * h + g) * 256 + t];
-            }
-            // mul_to: one v_mul_f32 straight into its half of the (chunk A, chunk B) pair.  Left to the
-            // SLP vectoriser the two rounds become v_pk_mul_f32 on re-paired operands: ~100 v_mov per thread.
-            if (h == 0) {
-                d[4 * g + 0].x = mul_to(q.x, w.x);
-                d[4 * g + 1].x = mul_to(q.y, w.y);
-                d[4 * g + 2].x = mul_to(q.z, w.z);
-                d[4 * g + 3].x = mul_to(q.w, w.w);
-            } else {
-                d[4 * g + 0].y = mul_to(q.x, w.x);
-                d[4 * g + 1].y = mul_to(q.y, w.y);
-                d[4 * g + 2].y = mul_to(q.z, w.z);
-                d[4 * g + 3].y = mul_to(q.w, w.w);
+                const float4 w = wint[(8 * h + g) * 256 + t];
+                // mul_to: one v_mul_f32 straight into its half of the (chunk A, chunk B) pair.  Left to the
+                // SLP vectoriser the two rounds become v_pk_mul_f32 on re-paired operands: ~100 v_mov per thread.
+                if (h == 0) {
+                    d[4 * g + 0].x = mul_to(q.x, w.x);
+                    d[4 * g + 1].x = mul_to(q.y, w.y);
+                    d[4 * g + 2].x = mul_to(q.z, w.z);
+                    d[4 * g + 3].x = mul_to(q.w, w.w);
+                } else {
+                    d[4 * g + 0].y = mul_to(q.x, w.x);
+                    d[4 * g + 1].y = mul_to(q.y, w.y);
+                    d[4 * g + 2].y = mul_to(q.z, w.z);
+                    d[4 * g + 3].y = mul_to(q.w, w.w);
+                }
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// n1 += m1 * y, n2 += m2 * y with (m1, m2) one wave-uniform tap pair in an aligned SGPR pair: the halves are picked
-// with op_sel.  Written as `m1 * y` the compiler first copies every odd-numbered SGPR into an even one (one
-// s_mov_b32 per tap, 192 per frame and wave).
-__device__ __forceinline__ void tap_fma(v2f &n1, v2f &n2, const v2f tap, const v2f y)
+// Predictor taps.  (m1, m2) is one wave-uniform tap pair in an aligned SGPR pair; the chunk-end states of chunk A and
+// chunk B (from zero state) accumulate as (z1, z2) pairs: nA += tap * y.x, nB += tap * y.y.  Eight taps in one statement
+// (the compiler pads a wait state after every asm statement whose output the next one reads; 32 single-tap statements =
+// 32 pads per section).  Two accumulator sets alternate: a dependent FMA every fourth instruction.
+__device__ __forceinline__ void tap_fma8(v2f &nAa, v2f &nBa, v2f &nAb, v2f &nBb, const v2f (&tp)[8], const v2f (&y)[8])
 {
-    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
-        : "+v"(n1), "+v"(n2) : "s"(tap), "v"(y));
-}
-
-// Eight taps in one statement (the compiler pads a wait state after every asm statement whose output the next one
-// reads; 32 single-tap statements = 32 pads per section).  Two accumulator pairs alternate: a dependent FMA every
-// fourth instruction.
-__device__ __forceinline__ void tap_fma8(v2f &n1a, v2f &n2a, v2f &n1b, v2f &n2b, const v2f (&tp)[8], const v2f (&y)[8])
-{
-#define SA_TAP(ACC1, ACC2, T, Y)                                                               \
-    "v_pk_fma_f32 %[" ACC1 "], %[" T "], %[" Y "], %[" ACC1 "] op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t" \
-    "v_pk_fma_f32 %[" ACC2 "], %[" T "], %[" Y "], %[" ACC2 "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define SA_TAP(ACCA, ACCB, T, Y)                                                               \
+    "v_pk_fma_f32 %[" ACCA "], %[" T "], %[" Y "], %[" ACCA "] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t" \
+    "v_pk_fma_f32 %[" ACCB "], %[" T "], %[" Y "], %[" ACCB "] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
     asm(SA_TAP("a1", "a2", "t0", "y0") SA_TAP("b1", "b2", "t1", "y1") SA_TAP("a1", "a2", "t2", "y2")
             SA_TAP("b1", "b2", "t3", "y3") SA_TAP("a1", "a2", "t4", "y4") SA_TAP("b1", "b2", "t5", "y5")
                 SA_TAP("a1", "a2", "t6", "y6") SA_TAP("b1", "b2", "t7", "y7") ""
-        : [a1] "+v"(n1a), [a2] "+v"(n2a), [b1] "+v"(n1b), [b2] "+v"(n2b)
+        : [a1] "+v"(nAa), [a2] "+v"(nBa), [b1] "+v"(nAb), [b2] "+v"(nBb)
         : [t0] "s"(tp[0]), [t1] "s"(tp[1]), [t2] "s"(tp[2]), [t3] "s"(tp[3]), [t4] "s"(tp[4]), [t5] "s"(tp[5]), [t6] "s"(tp[6]),
           [t7] "s"(tp[7]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4]), [y5] "v"(y[5]),
           [y6] "v"(y[6]), [y7] "v"(y[7]));
@@ -169,23 +202,23 @@ __device__ __forceinline__ void tap_fma8(v2f &n1a, v2f &n2a, v2f &n1b, v2f &n2b,
 // The wave-uniform constants of one section, read one section ahead (while the previous section's loops run)
 // so that their scalar-load latency is not on the path between two sections.
 struct SecConsts {
-    float pc0, pc1, pc2, pc3, mb0, mb1, mb2, mb3, b0, b1, b2, a1, a2, flags_bits;     // flags travel as raw bits
+    v2f pc0, pc1, mb0, mb1;            // columns of Pc and of T^-1
+    float b0, b1, b2, a1, a2, flags_bits;     // flags travel as raw bits
 };
 template <typename SecT>
 __device__ __forceinline__ SecConsts load_consts(const SecT &k)
 {
-    return {k.pc[0], k.pc[1], k.pc[2], k.pc[3], k.mback[0], k.mback[1], k.mback[2], k.mback[3],
+    return {v2f{k.pc[0], k.pc[1]}, v2f{k.pc[2], k.pc[3]}, v2f{k.mback[0], k.mback[1]}, v2f{k.mback[2], k.mback[3]},
             k.c[0], k.c[1], k.c[2], k.c[3], k.c[4], __builtin_bit_cast(float, k.flags)};
 }
 __device__ __forceinline__ void pin_consts(const SecConsts &c)
 {
-    asm volatile("" ::"s"(c.pc0), "s"(c.pc1), "s"(c.pc2), "s"(c.pc3), "s"(c.mb0), "s"(c.mb1), "s"(c.mb2), "s"(c.mb3),
-                 "s"(c.b1), "s"(c.a1), "s"(c.a2), "s"(c.flags_bits));
+    asm volatile("" ::"s"(c.pc0), "s"(c.pc1), "s"(c.mb0), "s"(c.mb1), "s"(c.b1), "s"(c.a1), "s"(c.a2), "s"(c.flags_bits));
 }
 
 // One cascade section, in place on the thread's two chunks.
-//   z1,z2 (in) : predicted end states of chunk A (.x) and chunk B (.y) from zero state
-//   z1,z2 (out): the same for the NEXT section
+//   zA, zB (in) : predicted end states (z1, z2) of chunk A and chunk B from zero state, pole coordinates
+//   zA, zB (out): the same for the NEXT section
 //   c  (in)    : this section's constants;   cn (out): the next section's, requested here
 // Two loops: the recursion (3 scalar constants), then the next section's predictor over the fresh outputs (its
 // 32 tap pairs, requested before the recursion so that they arrive under it).  Fused into one loop the 64 tap
@@ -194,53 +227,45 @@ __device__ __forceinline__ void pin_consts(const SecConsts &c)
 template <bool PREDICT_NEXT, bool UNIT, typename SecT>
 __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const SecT &knext, const SecConsts c,
                                             SecConsts &cn, const float4 lanep, float2 *scr_s, int lane, int wave,
-                                            v2f &z1, v2f &z2)
+                                            v2f &zA, v2f &zB)
 {
-    // state after both chunks of this thread, from zero state: zT = Pc zA + zB
-    float t1 = __builtin_fmaf(c.pc0, z1.x, __builtin_fmaf(c.pc1, z2.x, z1.y));
-    float t2 = __builtin_fmaf(c.pc2, z1.x, __builtin_fmaf(c.pc3, z2.x, z2.y));
+    // state after both chunks of this thread, from zero state: T = Pc zA + zB
+    v2f T = mv_s(c.pc0, c.pc1, zA, zB);
     // inclusive affine scan inside the 16-lane row; levels whose transition power has decayed below
     // float resolution are skipped (wave-uniform flags from the host)
     const int flags = __builtin_bit_cast(int, c.flags_bits);
-    if (!(flags & 1)) scan_level<1>(t1, t2, k.plev[0]);
-    if (!(flags & 2)) scan_level<2>(t1, t2, k.plev[1]);
-    if (!(flags & 4)) scan_level<4>(t1, t2, k.plev[2]);
-    if (!(flags & 8)) scan_level<8>(t1, t2, k.plev[3]);
+    if (!(flags & 1)) scan_level<1>(T, k.plev[0]);
+    if (!(flags & 2)) scan_level<2>(T, k.plev[1]);
+    if (!(flags & 4)) scan_level<4>(T, k.plev[2]);
+    if (!(flags & 8)) scan_level<8>(T, k.plev[3]);
     const int row = 4 * wave + (lane >> 4);
-    if ((lane & 15) == 15) scr_s[row] = make_float2(t1, t2);
-    const float e1 = row_shr<1>(t1), e2 = row_shr<1>(t2);       // exclusive: state before this thread, row-local
+    if ((lane & 15) == 15) scr_s[row] = make_float2(T.x, T.y);
+    const v2f e = {row_shr<1>(T.x), row_shr<1>(T.y)};            // exclusive: state before this thread, row-local
     lds_barrier();
-    float c1, c2;
+    v2f cst;
     if (flags & SA_IIR_SKIP_ROWSCAN) {
         // a row (1024 samples) outlasts the section's memory: the row starts from the previous row's total
         const float2 tt = scr_s[(row - 1) & 15];
-        c1 = tt.x;
-        c2 = tt.y;
+        cst = v2f{tt.x, tt.y};
     } else {
         // scan over the 16 row totals (every row of every wave repeats it: 16 lanes, 4 DPP levels)
         const float2 tt = scr_s[lane & 15];
-        float r1 = tt.x, r2 = tt.y;
-        scan_level<1>(r1, r2, k.prow[0]);
-        scan_level<2>(r1, r2, k.prow[1]);
-        scan_level<4>(r1, r2, k.prow[2]);
-        scan_level<8>(r1, r2, k.prow[3]);
+        v2f r = {tt.x, tt.y};
+        scan_level<1>(r, k.prow[0]);
+        scan_level<2>(r, k.prow[1]);
+        scan_level<4>(r, k.prow[2]);
+        scan_level<8>(r, k.prow[3]);
         // state at the start of this lane's row = inclusive result of the previous row
         const int src = (lane & 48) | ((row - 1) & 15);
-        c1 = lane_get(r1, src);
-        c2 = lane_get(r2, src);
+        cst = v2f{lane_get(r.x, src), lane_get(r.y, src)};
     }
-    if (row == 0) {
-        c1 = 0.f;
-        c2 = 0.f;
-    }
+    if (row == 0) cst = v2f{0.f, 0.f};
     // start state of chunk A: row-local part + P2^i * (row start state); chunk B: Pc sA + zA
-    const float a1s = __builtin_fmaf(lanep.x, c1, __builtin_fmaf(lanep.y, c2, e1));
-    const float a2s = __builtin_fmaf(lanep.z, c1, __builtin_fmaf(lanep.w, c2, e2));
-    const float b1s = __builtin_fmaf(c.pc0, a1s, __builtin_fmaf(c.pc1, a2s, z1.x));
-    const float b2s = __builtin_fmaf(c.pc2, a1s, __builtin_fmaf(c.pc3, a2s, z2.x));
-    // pole coordinates -> DF2T states of the recursion (sa_common.hpp)
-    const v2f q1 = {a1s, b1s}, q2 = {a2s, b2s};
-    v2f s1 = c.mb0 * q1 + c.mb1 * q2, s2 = c.mb2 * q1 + c.mb3 * q2;
+    const v2f aS = mv_v(v2f{lanep.x, lanep.y}, v2f{lanep.z, lanep.w}, cst, e);
+    const v2f bS = mv_s(c.pc0, c.pc1, aS, zA);
+    // pole coordinates -> DF2T states of the recursion (sa_common.hpp), re-paired as (chunk A, chunk B)
+    const v2f q1 = {aS.x, bS.x}, q2 = {aS.y, bS.y};
+    v2f s1 = c.mb0.x * q1 + c.mb1.x * q2, s2 = c.mb0.y * q1 + c.mb1.y * q2;
     // the next section's tap pairs: requested now, consumed after the recursion
     v2f tp[32];
     if constexpr (PREDICT_NEXT) {
@@ -266,15 +291,15 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     if constexpr (PREDICT_NEXT) {
         cn = load_consts(knext);
         // four accumulators: each chain sees a dependent FMA every fourth instruction
-        v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
+        v2f nAa = {0.f, 0.f}, nBa = {0.f, 0.f}, nAb = {0.f, 0.f}, nBb = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 32; j += 8) {
             const v2f t8[8] = {tp[j], tp[j + 1], tp[j + 2], tp[j + 3], tp[j + 4], tp[j + 5], tp[j + 6], tp[j + 7]};
             const v2f y8[8] = {d[j], d[j + 1], d[j + 2], d[j + 3], d[j + 4], d[j + 5], d[j + 6], d[j + 7]};
-            tap_fma8(n1a, n2a, n1b, n2b, t8, y8);
+            tap_fma8(nAa, nBa, nAb, nBb, t8, y8);
         }
-        z1 = n1a + n1b;
-        z2 = n2a + n2b;
+        zA = nAa + nAb;
+        zB = nBa + nBb;
         pin_consts(cn);
     }
 }
@@ -284,14 +309,14 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
 // through control-flow merges and cost ~190 register copies.
 template <int S, int NSEC, bool UNIT, typename PlanT>
 __device__ __forceinline__ void iir_sections(v2f (&d)[32], const PlanT &ka, const SaIirLaneTab *__restrict__ lt,
-                                             float2 *scr, int lane, int wave, v2f &z1, v2f &z2, const SecConsts c)
+                                             float2 *scr, int lane, int wave, v2f &zA, v2f &zB, const SecConsts c)
 {
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
         SecConsts cn = c;
         iir_section<(S + 1 < NSEC), UNIT>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + 16 * S, lane,
-                                          wave, z1, z2);
-        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, z1, z2, cn);
+                                          wave, zA, zB);
+        iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, zA, zB, cn);
     }
 }
 
@@ -301,7 +326,7 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const
 {
     // predictor for the first section (later ones run after the previous section's recursion)
     const SecConsts c0 = load_consts(ka.sec[0]);
-    v2f n1a = {0.f, 0.f}, n2a = {0.f, 0.f}, n1b = {0.f, 0.f}, n2b = {0.f, 0.f};
+    v2f nAa = {0.f, 0.f}, nBa = {0.f, 0.f}, nAb = {0.f, 0.f}, nBb = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         v2f t8[8], y8[8];
@@ -310,11 +335,11 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const
             t8[e] = v2f{ka.m0[j + e][0], ka.m0[j + e][1]};
             y8[e] = d[j + e];
         }
-        tap_fma8(n1a, n2a, n1b, n2b, t8, y8);
+        tap_fma8(nAa, nBa, nAb, nBb, t8, y8);
     }
-    v2f z1 = n1a + n1b, z2 = n2a + n2b;
+    v2f zA = nAa + nAb, zB = nBa + nBb;
     pin_consts(c0);
-    iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, z1, z2, c0);
+    iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, zA, zB, c0);
 }
 
 // Position of Z[k] inside the half image of the natural-order exchange.  Round r holds the rows

@@ -36,7 +36,9 @@ struct SaIirSecK {
     float c[5];            // b0,b1,b2,a1,a2
     int flags;
     float pad[2];
-    float pc[4];           // Pc, row-major p00,p01,p10,p11
+    // every 2x2 matrix below and in SaIirLaneTab::p is stored COLUMN-major (m00, m10, m01, m11): a column is an aligned
+    // register pair and a matrix-vector product is two packed FMAs (chain_f32.hip, mv_s)
+    float pc[4];           // Pc
     float mback[4];        // T^-1
     float plev[4][4];      // P2^(1,2,4,8)      in-row scan (DPP row_shr 1,2,4,8)
     float prow[4][4];      // Prow^(1,2,4,8)    scan over the 16 rows of a frame

@@ -252,7 +252,7 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         sp.c[0] = (float)b0; sp.c[1] = (float)b1; sp.c[2] = (float)b2; sp.c[3] = (float)a1; sp.c[4] = (float)a2;
         Mat2 M, T, A;
         pole_coordinates(a1, a2, &M, &T, &A);
-        put(sp.mback, M);
+        put_cm(sp.mback, M);
         double v0 = T.a * (b1 - a1 * b0) + T.b * (b2 - a2 * b0);      // T Bv
         double v1 = T.c * (b1 - a1 * b0) + T.d * (b2 - a2 * b0);
         float (*mdst)[2] = s == 0 ? plan->m0 : plan->sec[s - 1].mnext;       // taps of section s ride with section s-1
@@ -265,7 +265,7 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         const Mat2 Pc = mpow(A, SA_CHUNK);                  // one chunk
         const Mat2 P2 = mul(Pc, Pc);                        // one thread (two chunks)
         const Mat2 Prow = mpow(P2, 16);                     // one 16-lane row
-        put(sp.pc, Pc);
+        put_cm(sp.pc, Pc);
         Mat2 q = P2, qr = Prow;
         auto tiny = [](const Mat2 &m) {
             const double mx = std::fmax(std::fmax(std::fabs(m.a), std::fabs(m.b)), std::fmax(std::fabs(m.c), std::fabs(m.d)));
@@ -273,15 +273,15 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         };
         sp.flags = tiny(Prow) ? SA_IIR_SKIP_ROWSCAN : 0;
         for (int i = 0; i < 4; ++i) {                       // powers 1,2,4,8
-            put(sp.plev[i], q);
-            put(sp.prow[i], qr);
+            put_cm(sp.plev[i], q);
+            put_cm(sp.prow[i], qr);
             if (tiny(q)) sp.flags |= 1 << i;
             q = mul(q, q);
             qr = mul(qr, qr);
         }
         Mat2 pw = {1, 0, 0, 1};
         for (int i = 0; i < 16; ++i) {                      // lanetab[s][i] = P2^i
-            put(lt->p[s][i], pw);
+            put_cm(lt->p[s][i], pw);
             pw = mul(pw, P2);
         }
     }
@@ -647,16 +647,21 @@ int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
         const SaIirSecK &k = p.sec[s];
         for (int i = 0; i < 5; ++i) v.push_back(k.c[i]);
         put_i(k.flags); v.push_back(k.pad[0]); v.push_back(k.pad[1]);
-        v.insert(v.end(), k.pc, k.pc + 4);
-        v.insert(v.end(), k.mback, k.mback + 4);
-        v.insert(v.end(), &k.plev[0][0], &k.plev[0][0] + 16);
-        v.insert(v.end(), &k.prow[0][0], &k.prow[0][0] + 16);
+        auto rm = [&](const float *m) { v.push_back(m[0]); v.push_back(m[2]); v.push_back(m[1]); v.push_back(m[3]); };   // stored column-major
+        rm(k.pc);
+        rm(k.mback);
+        for (int i = 0; i < 4; ++i) rm(k.plev[i]);
+        for (int i = 0; i < 4; ++i) rm(k.prow[i]);
     }
     for (int s = 0; s < SA_MAXSEC; ++s) {
         const float (*m)[2] = s == 0 ? p.m0 : p.sec[s - 1].mnext;
         v.insert(v.end(), &m[0][0], &m[0][0] + 2 * SA_CHUNK);
     }
-    v.insert(v.end(), &lt.p[0][0][0], &lt.p[0][0][0] + SA_MAXSEC * 16 * 4);
+    for (int sct = 0; sct < SA_MAXSEC; ++sct)
+        for (int i = 0; i < 16; ++i) {
+            const float *m = lt.p[sct][i];
+            v.push_back(m[0]); v.push_back(m[2]); v.push_back(m[1]); v.push_back(m[3]);
+        }
     const int n = (int)v.size();
     if (out && cap > 0) std::memcpy(out, v.data(), sizeof(float) * (size_t)(cap < n ? cap : n));
     return n;
