@@ -342,6 +342,50 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const
     iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, zA, zB, c0);
 }
 
+// Half-spectrum outputs (SA_OUT_MAG_HALF, SA_OUT_SPEC_HALF: the numpy.fft.rfft layout, rows of 8193 elements).  A row is
+// 4- or 8-byte aligned only (every other row of complex values starts 8 bytes off a 16-byte boundary), so 16-byte stores
+// straight from the registers are not possible and element-wise stores put two half-written lines into every wave
+// instruction: round 2 measured twice the L2 write requests and +46 % HBM write bytes against the full-magnitude output.
+// Here the 2048 consecutive bins a round produces per segment go through LDS in natural order and leave as 16-byte stores
+// at ABSOLUTE 16-byte boundaries, 1 KiB contiguous per wave instruction; only the (at most n - 1) elements in front of the
+// first and behind the last boundary of the segment are stored one by one.
+//   seg: the segment's 2048 elements in LDS;  g: where its first element goes in the output row
+template <typename Et>
+__device__ __forceinline__ void stream_out_segment(const Et *__restrict__ seg, Et *__restrict__ g, int t)
+{
+    constexpr int n = 16 / (int)sizeof(Et);                         // elements per 16-byte unit
+    const int h = (int)(((size_t)g / sizeof(Et)) & (size_t)(n - 1)); // unit u holds elements n u - h .. n u - h + n - 1
+    constexpr int per_thread = 2048 / n / kThreads;
+#pragma unroll
+    for (int i = 0; i <= per_thread; ++i) {
+        const int u = t + kThreads * i;
+        if (i == per_thread && (h == 0 || t != 0)) break;           // the unit behind the last full one: thread 0, if any
+        const int e0 = n * u - h;
+        if (e0 >= 0 && e0 + n <= 2048) {
+            float v[4];
+            if constexpr (n == 2) {
+                const float2 a = reinterpret_cast<const float2 *>(seg)[e0], b = reinterpret_cast<const float2 *>(seg)[e0 + 1];
+                v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float *>(seg)[e0 + j];
+            }
+            store_nt(reinterpret_cast<float *>(g + e0), v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < n; ++j)
+                if (e0 + j >= 0 && e0 + j < 2048) {
+                    if constexpr (n == 2) {
+                        const float2 a = reinterpret_cast<const float2 *>(seg)[e0 + j];
+                        store_nt(reinterpret_cast<float2 *>(g + e0 + j), a.x, a.y);
+                    } else {
+                        store_nt(reinterpret_cast<float *>(g + e0 + j), reinterpret_cast<const float *>(seg)[e0 + j]);
+                    }
+                }
+        }
+    }
+}
+
 // Position of Z[k] inside the half image of the natural-order exchange.  Round r holds the rows
 // d = k >> 9 of {0..3, 12..15} (r = 0) or {4..11} (r = 1), compacted to d' = (d + 4r) & 7; inside a row
 // the 512 entries are padded by one per 32.  With q = k - 2048 r for the low member of a pair and
@@ -542,6 +586,8 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         }
         lds_barrier();
         SA_STAMP(9 + r);
+        constexpr bool HALF = OUT == SA_OUT_MAG_HALF || OUT == SA_OUT_SPEC_HALF;
+        cf Rs[2][5], Is[2][5];                                 // half-spectrum outputs: both groups wait for the staging pass
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int q0 = 4 * (t + 256 * jj);                 // k0 - 2048 r: bins q0 .. q0+4 of this round
@@ -574,7 +620,59 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
             cf R[5], I[5];
 #pragma unroll
             for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], R[e], I[e]);
-            split_store<OUT>(R, I, out, f, k0);
+            if constexpr (!HALF) {
+                split_store<OUT>(R, I, out, f, k0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    Rs[jj][e] = R[e];
+                    Is[jj][e] = I[e];
+                }
+            }
+        }
+        if constexpr (HALF) {
+            // stage the round's two runs of 2048 bins in natural order (stream_out_segment):
+            //   segment 0 = bins 2048 r .. 2048 r + 2047           P_e = X[k0 + e], e < 4, at q0 + e
+            //   segment 1 = bins 6144 - 2048 r .. 8191 - 2048 r    conj Q_e = X[8192 - k0 - e], e = 1..4, at 2048 - q0 - e
+            lds_barrier();                                     // every thread is done with the Z image
+            if constexpr (OUT == SA_OUT_SPEC_HALF) {
+                float4 *s0 = reinterpret_cast<float4 *>(smem), *s1 = reinterpret_cast<float4 *>(smem + 2048 * 8);
+                float2 *orow = reinterpret_cast<float2 *>(out) + (size_t)f * (SA_MC + 1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int q0 = 4 * (t + 256 * jj);
+                    const cf(&R)[5] = Rs[jj];
+                    const cf(&I)[5] = Is[jj];
+                    s0[q0 / 2] = make_float4(R[0].x, I[0].x, R[1].x, I[1].x);
+                    s0[q0 / 2 + 1] = make_float4(R[2].x, I[2].x, R[3].x, I[3].x);
+                    s1[(2044 - q0) / 2] = make_float4(R[4].y, -I[4].y, R[3].y, -I[3].y);
+                    s1[(2044 - q0) / 2 + 1] = make_float4(R[2].y, -I[2].y, R[1].y, -I[1].y);
+                    if (r == 0 && q0 == 0) store_nt(orow + SA_MC, R[0].y, -I[0].y);          // X[8192]
+                }
+                lds_barrier();
+                stream_out_segment(reinterpret_cast<const float2 *>(smem), orow + 2048 * r, t);
+                stream_out_segment(reinterpret_cast<const float2 *>(smem + 2048 * 8), orow + 6144 - 2048 * r, t);
+            } else {
+                float4 *s0 = reinterpret_cast<float4 *>(smem), *s1 = reinterpret_cast<float4 *>(smem + 2048 * 4);
+                float *orow = reinterpret_cast<float *>(out) + (size_t)f * (SA_MC + 1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int q0 = 4 * (t + 256 * jj);
+                    float mp[5], mq[5];
+#pragma unroll
+                    for (int e = 0; e < 5; ++e) {
+                        const cf m2 = safft::pk_fma(Is[jj][e], Is[jj][e], Rs[jj][e] * Rs[jj][e]);          // (|P|^2, |Q|^2)
+                        mp[e] = fast_sqrt(m2.x);
+                        mq[e] = fast_sqrt(m2.y);
+                    }
+                    s0[q0 / 4] = make_float4(mp[0], mp[1], mp[2], mp[3]);
+                    s1[(2044 - q0) / 4] = make_float4(mq[4], mq[3], mq[2], mq[1]);
+                    if (r == 0 && q0 == 0) store_nt(orow + SA_MC, mq[0]);
+                }
+                lds_barrier();
+                stream_out_segment(reinterpret_cast<const float *>(smem), orow + 2048 * r, t);
+                stream_out_segment(reinterpret_cast<const float *>(smem + 2048 * 4), orow + 6144 - 2048 * r, t);
+            }
         }
     }
     SA_STAMP(11);

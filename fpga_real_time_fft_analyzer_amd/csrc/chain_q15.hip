@@ -491,12 +491,121 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
     "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"                                                             \
     "s_mov_b64 exec, %[sv]\n\t"
 
+// The same block when the port tap B1 is zero in BOTH coefficient sets (the fixed ALPHA / BETA cascade of mode 0x00,
+// imp/filter_pkg.vhd:54-68; the identity stages have B1 = 0 anyway): t(0, v) = 0 exactly, so the product D and the add G
+// drop out and s2 = hi(p2) + hi(p3) is one instruction, issued BEFORE this block's B and E overwrite the previous
+// block's p2 and p3.  Seven instructions per step, bit-identical results (new/filter_iir_cust.vhd:96-117 truncates every
+// product separately: a zero tap contributes a zero term).  The host picks this form per launch from the coefficient
+// bytes (sa_launch_filter_q15); any other upload runs the nine-instruction block.
+// Order and s_nop placement timed on the real kernel (tools/ab_q15.py, profiles/r3_q7_nb1_sweep.txt): SA_Q7_NB1_ORDER, SA_Q7_NB1_NOPS.
+#ifndef SA_Q7_NB1_ORDER
+#define SA_Q7_NB1_ORDER 3
+#endif
+#ifndef SA_Q7_NB1_NOPS
+#define SA_Q7_NB1_NOPS 0x00
+#endif
+#define SA_NBN(BIT) ((SA_Q7_NB1_NOPS >> (BIT)) & 1)
+#if SA_Q7_NB1_NOPS & 0x01
+#define SA_M0 "s_nop 0\n\t"
+#else
+#define SA_M0
+#endif
+#if SA_Q7_NB1_NOPS & 0x02
+#define SA_M1 "s_nop 0\n\t"
+#else
+#define SA_M1
+#endif
+#if SA_Q7_NB1_NOPS & 0x04
+#define SA_M2 "s_nop 0\n\t"
+#else
+#define SA_M2
+#endif
+#if SA_Q7_NB1_NOPS & 0x08
+#define SA_M3 "s_nop 0\n\t"
+#else
+#define SA_M3
+#endif
+#if SA_Q7_NB1_NOPS & 0x10
+#define SA_M4 "s_nop 0\n\t"
+#else
+#define SA_M4
+#endif
+#if SA_Q7_NB1_NOPS & 0x20
+#define SA_M5 "s_nop 0\n\t"
+#else
+#define SA_M5
+#endif
+#if SA_Q7_NB1_NOPS & 0x40
+#define SA_M6 "s_nop 0\n\t"
+#else
+#define SA_M6
+#endif
+#define SA_Q7I_H(Y) "v_add_u32_sdwa " Y ", %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"
+#define SA_Q7I_I "v_add_u32_sdwa %[s2], %[p2], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+#define SA_Q7I_B(H1) "v_mul_i32_i24_dpp %[p2], " H1 ", %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+#define SA_Q7I_C(Y) "v_mul_i32_i24_dpp %[p0], " Y ", %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+#define SA_Q7I_A(Y) "v_mad_i32_i24 %[p4], " Y ", %[nA1], %[k]\n\t"
+#define SA_Q7I_E(Y) "v_mad_i32_i24 %[p3], " Y ", %[nA0], %[k]\n\t"
+#define SA_Q7I_F "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+#if SA_Q7_NB1_ORDER == 0      // H I B C A E F
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_A(Y) SA_M4 SA_Q7I_E(Y) SA_M5 SA_Q7I_F SA_M6
+#elif SA_Q7_NB1_ORDER == 1    // H I B C A F E   (F one earlier: one instruction between F and the next block's H)
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_A(Y) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
+#elif SA_Q7_NB1_ORDER == 2    // H I A B C F E   (the feedback product first)
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_A(Y) SA_M2 SA_Q7I_B(H1) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
+#elif SA_Q7_NB1_ORDER == 3    // H I B A C E F
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_A(Y) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_E(Y) SA_M5 SA_Q7I_F SA_M6
+#elif SA_Q7_NB1_ORDER == 4    // H I A C B F E   (every reader at least one instruction behind its writer, the DPP read two)
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_A(Y) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_B(H1) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
+#else                         // H I E A C B F
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_E(Y) SA_M2 SA_Q7I_A(Y) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_B(H1) SA_M5 SA_Q7I_F SA_M6
+#endif
+#define SA_Q7_NB1GROUP(RD_OFF, WR_OFF0, WR_OFF1)                                                                       \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                         \
+    "v_cndmask_b32_e64 %[t], %[t], %[xin], %[inm]\n\t"                                                                 \
+    "ds_read_u16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
+    SA_Q7_NB1BLOCK("v52", "v59") SA_Q7_NB1BLOCK("v53", "v52") SA_Q7_NB1BLOCK("v54", "v53") SA_Q7_NB1BLOCK("v55", "v54")  \
+    SA_Q7_NB1BLOCK("v56", "v55") SA_Q7_NB1BLOCK("v57", "v56") SA_Q7_NB1BLOCK("v58", "v57") SA_Q7_NB1BLOCK("v59", "v58")  \
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
+    "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF0 "\n\t"                                                             \
+    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"                                                             \
+    "s_mov_b64 exec, %[sv]\n\t"
+
 // xa: LDS byte address of the lane's refill slot of the tile's first group; ra: of the ring slot of its outputs
+template <bool NOB1>
 __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, unsigned ra, unsigned long long in_mask,
                                         unsigned long long out_mask, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
 {
     int xin, cnt = kTile / 32;
     unsigned long long saved;
+    if constexpr (NOB1) {
+        // the seven-instruction block: p1 and u are not touched (p1 stays the zero it is: the drain group's block reads it)
+        asm volatile(
+            "v_mov_b32 v52, %[y0]\n\tv_mov_b32 v53, %[y1]\n\tv_mov_b32 v54, %[y2]\n\tv_mov_b32 v55, %[y3]\n\t"
+            "v_mov_b32 v56, %[y4]\n\tv_mov_b32 v57, %[y5]\n\tv_mov_b32 v58, %[y6]\n\tv_mov_b32 v59, %[y7]\n\t"
+            "ds_read_u16 %[xin], %[xa]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            ".p2align 6\n"
+            "1:\n\t"
+            SA_Q7_NB1GROUP("16", "0", "16") SA_Q7_NB1GROUP("32", "32", "48") SA_Q7_NB1GROUP("48", "64", "80") SA_Q7_NB1GROUP("64", "96", "112")
+            "v_add_u32 %[xa], 64, %[xa]\n\t"
+            "v_add_u32 %[ra], 0x80, %[ra]\n\t"
+            "s_add_i32 %[cnt], %[cnt], -1\n\t"
+            "s_cmp_lg_u32 %[cnt], 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mov_b32 %[y0], v52\n\tv_mov_b32 %[y1], v53\n\tv_mov_b32 %[y2], v54\n\tv_mov_b32 %[y3], v55\n\t"
+            "v_mov_b32 %[y4], v56\n\tv_mov_b32 %[y5], v57\n\tv_mov_b32 %[y6], v58\n\tv_mov_b32 %[y7], v59"
+            : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]),
+              [y7] "+v"(y[7]), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p2] "+v"(c.p2), [p3] "+v"(c.p3), [p4] "+v"(c.p4),
+              [t] "+v"(c.t), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt), [sv] "=&s"(saved)
+            : [cB2] "v"(cB2), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask), [outm] "s"(out_mask)
+            : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+        // hand-over to the nine-instruction block of the drain group: its G adds hi(p1) = 0 and hi(p2) of the last B
+        // into u BEFORE its I -- consistent with what the last I of this loop left in s2 only if u is rebuilt the same way,
+        // which G does from p1, p2 itself.  Nothing to fix up.
+        return;
+    }
     asm volatile(
         "v_mov_b32 v52, %[y0]\n\tv_mov_b32 v53, %[y1]\n\tv_mov_b32 v54, %[y2]\n\tv_mov_b32 v55, %[y3]\n\t"
         "v_mov_b32 v56, %[y4]\n\tv_mov_b32 v57, %[y5]\n\tv_mov_b32 v58, %[y6]\n\tv_mov_b32 v59, %[y7]\n\t"
@@ -546,6 +655,7 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+template <bool NOB1>
 __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                    int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
 {
@@ -634,7 +744,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         // group of a tile requests the slots after its half of the ring (the other half, or the row's 8-element
         // pad): a valid address whose value is not used.
         const int i0 = (k & 1) * kTile;
-        if (live) q7_tile(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
+        if (live) q7_tile<NOB1>(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
         else group(k * kTile, xrow[i0]);
         wave_lds_sync();
         if (k >= 1) q7_flush_tile(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane);
@@ -894,9 +1004,19 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
         hipExtLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, nullptr, stop, 0, in, out_time, batch, p, t.rom);
     } else {
         const int per_wg = kFramesPerWave * kV2Waves;
-        hipExtLaunchKernelGGL(filter_q7_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr, stop, 0, in,
-                              out_time,
-                           batch, p, t.rom);
+        // B1 = 0 in both coefficient sets (wire order b0,b1,b2,a0,a1,a2 per set): the seven-instruction step
+        const bool nob1 = p.c12[1] == 0 && p.c12[7] == 0;
+#ifdef SA_AB_Q7_NO_ELISION            // A/B builds only
+        const bool use_nb1 = false;
+#else
+        const bool use_nb1 = nob1;
+#endif
+        if (use_nb1)
+            hipExtLaunchKernelGGL(filter_q7_kernel<true>, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr,
+                                  stop, 0, in, out_time, batch, p, t.rom);
+        else
+            hipExtLaunchKernelGGL(filter_q7_kernel<false>, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr,
+                                  stop, 0, in, out_time, batch, p, t.rom);
     }
     return hipGetLastError();
 }

@@ -107,6 +107,41 @@ def test_random_coefficient_uploads(ch, torch_mod, oracle):
         assert np.array_equal(ch.process_q15(_dev(torch_mod, x)).cpu().numpy(), iq_ref), (case, c12)
 
 
+def test_zero_tap_uploads_take_the_short_step_and_stay_exact(ch, torch_mod, oracle):
+    """The cascade kernel drops the product and the add of port tap B1 when it is zero in BOTH coefficient sets (the
+    fixed ALPHA / BETA cascade of mode 0x00, imp/filter_pkg.vhd:54-68: seven instructions per step instead of nine).
+    t(0, v) = 0 exactly (new/filter_iir_cust.vhd:96-117 truncates every product separately), so results must not move:
+    random uploads with B1 = 0 in both sets (short step), in one set only and in neither (long step), plus other zero
+    taps, all bit-exact against the integer model; mode 0x00 itself equals the same bytes uploaded in mode 0xA1."""
+    rng = np.random.default_rng(777)
+    x = rng.integers(-32768, 32768, (3, N)).astype(np.int16)
+    x[1] = rng.integers(-2048, 2048, N)
+    xd = _dev(torch_mod, x)
+    ch.set_filter_mode(0xA1)
+    for case in range(36):
+        c12 = rng.integers(-128, 128, 12).astype(np.int8)            # wire order b0,b1,b2,a0,a1,a2 per set
+        kind = case % 4
+        if kind == 0:
+            c12[1] = c12[7] = 0                                      # short step
+        elif kind == 1:
+            c12[1] = 0                                               # one set only: long step
+        elif kind == 2:
+            c12[1] = c12[7] = 0
+            c12[rng.integers(0, 12)] = 0                             # another zero tap on top
+            c12[1] = c12[7] = 0
+        ch.load_coeffs_q7(c12)
+        iq_ref, t_ref = oracle.chain_q15(x, None, 0, 0xA1, c12, None, want_time=True)
+        assert np.array_equal(ch.filter_q15(xd).cpu().numpy(), t_ref), (case, c12)
+        assert np.array_equal(ch.process_q15(xd).cpu().numpy(), iq_ref), (case, c12)
+    default = np.array([-14, 0, 14, 107, 21, 127, -15, 0, 15, 107, -21, 127], np.int8)      # imp/filter_pkg.vhd:54-68
+    ch.load_coeffs_q7(default)
+    up = ch.process_q15(xd).cpu().numpy()
+    ch.set_filter_mode(0x00)
+    assert np.array_equal(ch.process_q15(xd).cpu().numpy(), up)
+    iq_ref, _ = oracle.chain_q15(x, None, 0, 0x00, None, None, want_time=True)
+    assert np.array_equal(up, iq_ref)
+
+
 def test_random_wide_cascades(ch, torch_mod, oracle):
     """Wide mode (0xA2): random Q2.14 cascades of 1..6 sections, any int16 tap (saturating accumulators make
     unstable ones well defined), both window modes, bit-exact against the integer model."""
