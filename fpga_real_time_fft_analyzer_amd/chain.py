@@ -59,11 +59,17 @@ class SpectrumChain:
         if rc != abi.SA_OK:
             raise SpecanError(rc, self._lib.sa_last_error(None).decode())
         self._h = h
+        self.control_generation = 0        # bumped by every call that changes what the path computes (virtual_fpga.py)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
         if rc != abi.SA_OK:
             raise SpecanError(rc, self._lib.sa_last_error(self._h).decode())
+
+    def _ctl(self, rc: int):
+        """_check for the calls that change what the path computes: virtual_fpga.py drops frames computed ahead."""
+        self._check(rc)
+        self.control_generation += 1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -99,7 +105,7 @@ class SpectrumChain:
         """0x00 default / 0xA1 custom / 0xB1 none (new/command_control.vhd:53-58); 0xA2 wide."""
         if not 0 <= int(cmd) <= 255:
             raise SpecanError(abi.SA_EINVAL, "filter command must be one byte")
-        self._check(self._lib.sa_set_filter_mode(self._h, int(cmd)))
+        self._ctl(self._lib.sa_set_filter_mode(self._h, int(cmd)))
 
     @property
     def filter_mode(self) -> int:
@@ -116,7 +122,7 @@ class SpectrumChain:
         if a.min() < -128 or a.max() > 127:
             raise SpecanError(abi.SA_EINVAL, "coefficients must fit int8")
         a8 = np.ascontiguousarray(a.astype(np.int8))
-        self._check(self._lib.sa_load_coeffs_q7(self._h, a8.ctypes.data_as(C.POINTER(C.c_int8))))
+        self._ctl(self._lib.sa_load_coeffs_q7(self._h, a8.ctypes.data_as(C.POINTER(C.c_int8))))
 
     def coeffs_q7(self) -> np.ndarray:
         a = np.zeros(12, np.int8)
@@ -128,7 +134,7 @@ class SpectrumChain:
         (0xA5, imp/sequ2.vhd:216) seen outside coefficient uploads."""
         buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_uint8 * 1)()
         n = C.c_int(0)
-        self._check(self._lib.sa_feed_command_bytes(self._h, buf, len(data), C.byref(n)))
+        self._ctl(self._lib.sa_feed_command_bytes(self._h, buf, len(data), C.byref(n)))
         return n.value
 
     def feed_command_bytes_ex(self, data: bytes) -> "abi.CmdEvents":
@@ -136,6 +142,8 @@ class SpectrumChain:
         buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data)) if len(data) else (C.c_uint8 * 1)()
         ev = abi.CmdEvents()
         self._check(self._lib.sa_feed_command_bytes_ex(self._h, buf, len(data), C.byref(ev)))
+        if ev.control_changed:
+            self.control_generation += 1
         return ev
 
     @property
@@ -158,24 +166,24 @@ class SpectrumChain:
     def load_sos(self, sos):
         """Wide float format: up to 6 sections, scipy rows [b0,b1,b2,a0,a1,a2] (float64)."""
         s = np.ascontiguousarray(np.asarray(sos, np.float64).reshape(-1, 6))
-        self._check(self._lib.sa_load_sos_f64(self._h, s.ctypes.data_as(C.POINTER(C.c_double)), s.shape[0]))
+        self._ctl(self._lib.sa_load_sos_f64(self._h, s.ctypes.data_as(C.POINTER(C.c_double)), s.shape[0]))
 
     def load_sos_f32(self, sos):
         s = np.ascontiguousarray(np.asarray(sos, np.float32).reshape(-1, 6))
-        self._check(self._lib.sa_load_sos_f32(self._h, s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[0]))
+        self._ctl(self._lib.sa_load_sos_f32(self._h, s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[0]))
 
     def load_sos_q14(self, sos_q14):
         s = np.ascontiguousarray(np.asarray(sos_q14, np.int16).reshape(-1, 6))
-        self._check(self._lib.sa_load_sos_q14(self._h, s.ctypes.data_as(C.POINTER(C.c_int16)), s.shape[0]))
+        self._ctl(self._lib.sa_load_sos_q14(self._h, s.ctypes.data_as(C.POINTER(C.c_int16)), s.shape[0]))
 
     def set_window_q15(self, rom: Optional[np.ndarray]):
         if rom is None:
-            self._check(self._lib.sa_set_window_q15(self._h, None))
+            self._ctl(self._lib.sa_set_window_q15(self._h, None))
             return
         r = np.ascontiguousarray(rom, np.int16)
         if r.shape != (SA_N,):
             raise SpecanError(abi.SA_ESHAPE, "window ROM must have 16384 entries")
-        self._check(self._lib.sa_set_window_q15(self._h, r.ctypes.data_as(C.POINTER(C.c_int16))))
+        self._ctl(self._lib.sa_set_window_q15(self._h, r.ctypes.data_as(C.POINTER(C.c_int16))))
 
     def window_q15(self) -> np.ndarray:
         r = np.zeros(SA_N, np.int16)
@@ -184,15 +192,15 @@ class SpectrumChain:
 
     def set_window_f32(self, w: Optional[np.ndarray]):
         if w is None:
-            self._check(self._lib.sa_set_window_f32(self._h, None))
+            self._ctl(self._lib.sa_set_window_f32(self._h, None))
             return
         a = np.ascontiguousarray(w, np.float32)
         if a.shape != (SA_N,):
             raise SpecanError(abi.SA_ESHAPE, "window must have 16384 entries")
-        self._check(self._lib.sa_set_window_f32(self._h, a.ctypes.data_as(C.POINTER(C.c_float))))
+        self._ctl(self._lib.sa_set_window_f32(self._h, a.ctypes.data_as(C.POINTER(C.c_float))))
 
     def set_window_mode_q15(self, mode: int):
-        self._check(self._lib.sa_set_window_mode_q15(self._h, int(mode)))
+        self._ctl(self._lib.sa_set_window_mode_q15(self._h, int(mode)))
 
     def reserve(self, max_batch: int):
         self._check(self._lib.sa_reserve(self._h, int(max_batch)))

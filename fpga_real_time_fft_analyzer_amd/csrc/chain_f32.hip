@@ -495,9 +495,9 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     // factors W^(k1 t), k1 = 8a + b, are applied as two complex products per point; the 64 KiB table of all
     // of them (one 16-byte load per two points, every frame, through L2 -> L1) is what this replaces:
     // 24 KiB of anchors per frame, and the loads no longer sit between the butterflies and the exchange.
-    float4 an[6];
+    float4 an[5];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) an[i] = twT[i * 256 + t];
+    for (int i = 0; i < 5; ++i) an[i] = twT[i * 256 + t];
     safft::fft_dit<32>(a);
     {
         const cf wb[8] = {{1.f, 0.f}, {an[0].x, an[0].y}, {an[0].z, an[0].w}, {an[1].x, an[1].y},
@@ -509,9 +509,6 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
             if ((k1 >> 3) != 0) a[k1] = safft::cmul(a[k1], wa[k1 >> 3]);
         }
     }
-    // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255
-    // (its neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0)
-    const cf wP = {an[5].x, an[5].y}, wPn = {an[5].z, an[5].w};
     SA_STAMP(4);
     // ---- exchange A -> B in two rounds of 16 rows; FFT q of a thread lives in round q:
     //      k1 = 16q + 4 wave + kq, b = lo; inputs ldc[row][16 a + b] with row pitch 272
@@ -565,6 +562,14 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     safft::fft_dit<16>(p[0]);
     safft::fft_dit<16>(p[1]);
     SA_STAMP(8);
+    // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255 (its
+    // neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0).  Requested here, through an opaque copy
+    // of the thread index: loaded with the other anchors the four registers sit through three FFT passes (and spill in
+    // the half-spectrum variants).
+    int ts = t;
+    asm volatile("" : "+v"(ts));
+    const float4 an5 = twT[5 * 256 + ts];
+    const cf wP = {an5.x, an5.y}, wPn = {an5.z, an5.w};
     // ---- natural-order image + split step, two rounds: round 0 = d in {0..3,12..15} (bins k < 2048
     //      and their partners), round 1 = d in {4..11}.  Z[2048] and Z[6144] sit on the seam and
     //      travel through two side slots.
@@ -588,8 +593,11 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         SA_STAMP(9 + r);
         constexpr bool HALF = OUT == SA_OUT_MAG_HALF || OUT == SA_OUT_SPEC_HALF;
         cf Rs[2][5], Is[2][5];                                 // half-spectrum outputs: both groups wait for the staging pass
+        float mps[2][5], mqs[2][5];                            // (magnitudes only for SA_OUT_MAG_HALF: half the registers)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
+            // (half-spectrum outputs keep both groups' results until the staging pass: the groups must not be interleaved)
+            if (HALF && jj == 1) __builtin_amdgcn_sched_barrier(0);
             const int q0 = 4 * (t + 256 * jj);                 // k0 - 2048 r: bins q0 .. q0+4 of this round
             const int k0 = q0 + 2048 * r;
             // W_16384^(k0 + e) = W^(4 t) * W^(2048 r + 1024 jj + e): the second factor is the same for every
@@ -622,11 +630,18 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
             for (int e = 0; e < 5; ++e) split_eval(zk[e], zm[e], w[e], R[e], I[e]);
             if constexpr (!HALF) {
                 split_store<OUT>(R, I, out, f, k0);
-            } else {
+            } else if constexpr (OUT == SA_OUT_SPEC_HALF) {
 #pragma unroll
                 for (int e = 0; e < 5; ++e) {
                     Rs[jj][e] = R[e];
                     Is[jj][e] = I[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    const cf m2 = safft::pk_fma(I[e], I[e], R[e] * R[e]);          // (|P|^2, |Q|^2)
+                    mps[jj][e] = fast_sqrt(m2.x);
+                    mqs[jj][e] = fast_sqrt(m2.y);
                 }
             }
         }
@@ -658,13 +673,8 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int q0 = 4 * (t + 256 * jj);
-                    float mp[5], mq[5];
-#pragma unroll
-                    for (int e = 0; e < 5; ++e) {
-                        const cf m2 = safft::pk_fma(Is[jj][e], Is[jj][e], Rs[jj][e] * Rs[jj][e]);          // (|P|^2, |Q|^2)
-                        mp[e] = fast_sqrt(m2.x);
-                        mq[e] = fast_sqrt(m2.y);
-                    }
+                    const float(&mp)[5] = mps[jj];
+                    const float(&mq)[5] = mqs[jj];
                     s0[q0 / 4] = make_float4(mp[0], mp[1], mp[2], mp[3]);
                     s1[(2044 - q0) / 4] = make_float4(mq[4], mq[3], mq[2], mq[1]);
                     if (r == 0 && q0 == 0) store_nt(orow + SA_MC, mq[0]);

@@ -47,41 +47,3 @@ def frame_to_udp_payloads(frame_bytes: bytes) -> list[bytes]:
         raise ValueError("frame must be 65536 bytes")
     return [bytes([i]) + frame_bytes[i * PACKET_DATA_SIZE:(i + 1) * PACKET_DATA_SIZE]
             for i in range(PACKETS_PER_FRAME)]
-
-
-class FrameAssembler:
-    """Receiver-side counterpart with the semantics of MultiPacketAssembler (gui.py:308-352):
-    a frame completes when all indices have been seen; payloads of the wrong length or with an
-    index >= packet_count are ignored; slots older than ``evict_ms`` are dropped."""
-
-    def __init__(self, packet_count: int = PACKETS_PER_FRAME, packet_data_size: int = PACKET_DATA_SIZE,
-                 evict_ms: int = 3000):
-        self.packet_count = packet_count
-        self.packet_data_size = packet_data_size
-        self.evict_ms = evict_ms
-        self._slots: list[bytes | None] = [None] * packet_count
-        self._stamp = [0] * packet_count
-        self.frame_id = 0
-
-    def add(self, payload: bytes, now_ms: int):
-        if len(payload) != self.packet_data_size + 1:
-            return None
-        idx = payload[0]
-        if idx >= self.packet_count:
-            return None
-        self._slots[idx] = payload[1:]
-        self._stamp[idx] = now_ms
-        if all(s is not None for s in self._slots):
-            frame = b"".join(self._slots)          # type: ignore[arg-type]
-            self._slots = [None] * self.packet_count
-            self._stamp = [0] * self.packet_count
-            self.frame_id += 1
-            return frame
-        for i, s in enumerate(self._slots):
-            if s is not None and now_ms - self._stamp[i] > self.evict_ms:
-                self._slots[i] = None
-                self._stamp[i] = 0
-        return None
-
-    def get_completion_status(self):
-        return sum(s is not None for s in self._slots), self.packet_count

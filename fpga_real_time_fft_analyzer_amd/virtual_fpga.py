@@ -57,6 +57,7 @@ class VirtualFpga:
         self.source = source
         self.batch = int(batch)
         self._pending: list[bytes] = []
+        self._pending_generation = -1          # chain.control_generation the frames in _pending were computed under
         self._out_uart = bytearray()
         self._idle()
 
@@ -101,10 +102,15 @@ class VirtualFpga:
 
     # ---- acquisitions
     def _next_frame(self) -> bytes:
+        # frames computed ahead belong to the settings of their batch: ANY control change on the chain since then --
+        # command bytes, or a window / coefficient / mode call made directly on `self.chain` -- drops them
+        if self._pending_generation != self.chain.control_generation:
+            self._pending.clear()
         if not self._pending:
             x = np.ascontiguousarray(self.source(self.batch), dtype=np.int16).reshape(-1, frames.FFT_SIZE)
             iq = self.chain.process_q15(torch.from_numpy(x).to(self.chain.device))
             self._pending.extend(self.chain.frames_bytes(iq))
+            self._pending_generation = self.chain.control_generation
         return self._pending.pop(0)
 
     # ---- board -> host, UART

@@ -5,6 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
+from udp_collect import FrameCollector
 from conftest import N, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -298,6 +299,38 @@ def test_batch_beyond_two_gib(ch, torch_mod):
         del iq
 
 
+def test_virtual_fpga_drops_frames_computed_ahead_on_any_control_change(chain_cls, oracle):
+    """Frames are computed `batch` acquisitions at a time.  A control change made directly on the exposed chain (window
+    ROM, window mode, coefficients, filter mode) -- not only through command bytes -- must not let frames of the old
+    settings out: the next frame served already uses the new ones (loadable window ROM: new/hann.vhd:5-6)."""
+    from fpga_real_time_fft_analyzer_amd.virtual_fpga import VirtualFpga
+    rng = np.random.default_rng(18)
+    src = rng.integers(-2048, 2048, size=(8, N)).astype(np.int16)
+    taken = []
+
+    def source(n):
+        i = len(taken)
+        taken.extend(range(i, i + n))
+        return src[[j % 8 for j in range(i, i + n)]]
+
+    fpga = VirtualFpga(source, device=0, batch=4)
+    fpga.write(bytes([0xB1, 0x55]))                                     # bypass, Ethernet streaming
+    first = fpga.read_datagrams(1)
+    assert len(first) == 64 and len(taken) == 4                        # three more frames wait in the queue
+    rom = rng.integers(-32768, 32768, N).astype(np.int16)
+    fpga.chain.set_window_q15(rom)                                      # directly on the chain
+    dg = fpga.read_datagrams(1)
+    got = b"".join(d[1:] for d in dg)
+    assert len(taken) == 8                                              # the queue was dropped, a new batch acquired
+    want = oracle.chain_q15(src[4 % 8][None, :], rom, 0, 0xB1, None, None)[0].astype("<i2").tobytes()
+    assert got == want
+    fpga.chain.set_window_mode_q15(1)                                   # the unsigned-Hann reading of the same ROM
+    got = b"".join(d[1:] for d in fpga.read_datagrams(1))
+    want = oracle.chain_q15(src[8 % 8][None, :], rom, 1, 0xB1, None, None)[0].astype("<i2").tobytes()
+    assert got == want and len(taken) == 12
+    fpga.chain.close()
+
+
 def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
     """N1/N2: the board as gui.py sees it -- command bytes in, frames / datagrams out, sequenced like
     imp/sequ2.vhd: Ethernet after reset, 0x55 arms the UART and the first 0xA5 starts a CONTINUOUS byte stream
@@ -357,7 +390,7 @@ def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
     ser.write(bytes([0xB1, 0x55]))
     dg = fpga.read_datagrams(2)
     assert len(dg) == 128 and all(len(d) == 1025 for d in dg) and [d[0] for d in dg[:64]] == list(range(64))
-    asm = frames.FrameAssembler()
+    asm = FrameCollector()
     out = [fr for fr in (asm.add(d, 0) for d in dg) if fr is not None]
     assert len(out) == 2 and all(len(fr) == 65536 for fr in out)
     # UDP serve loop against a plain socket on the GUI's port layout (any free port here), capped frame rate
@@ -367,7 +400,7 @@ def test_virtual_fpga_uart_and_udp(chain_cls, torch_mod, oracle):
     th = threading.Thread(target=fpga.serve_udp, kwargs=dict(addr=rx.getsockname(), n_frames=3, fps_limit=200.0))
     t0 = __import__("time").monotonic()
     th.start()
-    asm, got_frames = frames.FrameAssembler(), []
+    asm, got_frames = FrameCollector(), []
     while len(got_frames) < 3:
         fr = asm.add(rx.recv(2048), 0)
         if fr is not None:

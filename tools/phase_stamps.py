@@ -51,8 +51,8 @@ def main():
     for i, lab in enumerate(labels):
         print(f"  {lab:7s} {NAMES.get(lab, ''):42s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}"
               f"  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
-    span = s[:, 12].max() - s[:, 0].min()
-    print(f"  whole grid span {span:.0f} clk; sum of WG lifetimes / span = {tot.sum() / span:.1f} resident WGs on average")
+    # (stamps 0..12 are s_memtime readings of each workgroup's own XCD: spans across workgroups are meaningful only in the
+    #  100 MHz s_memrealtime stamps 13 / 14, which tools/wg_timeline.py evaluates)
 
 
 if __name__ == "__main__":
