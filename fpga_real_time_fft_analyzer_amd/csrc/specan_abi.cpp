@@ -936,7 +936,7 @@ int sa_set_overlap(sa_handle *h, int depth)
         h->ov_unjoined[i] = false;
     }
     for (int i = 0; i < depth; ++i) {
-        if (!h->ov_stream[i]) SA_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[i], hipStreamNonBlocking));
+if (!h->ov_stream[i]) SA_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[i], hipStreamNonBlocking));
         if (!h->ov_fork[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_fork[i], hipEventDisableTiming));
         if (!h->ov_done[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_done[i], hipEventDisableTiming));
         // every slot starts with the workspace the handle already has somewhere
