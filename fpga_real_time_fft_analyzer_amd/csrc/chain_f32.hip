@@ -224,11 +224,20 @@ __device__ __forceinline__ void pin_consts(const SecConsts &c)
 // 32 tap pairs, requested before the recursion so that they arrive under it).  Fused into one loop the 64 tap
 // registers are live from the top of the section and, with the section constants, exceed the 102 SGPRs a wave
 // has: the compiler then reloads them piecemeal, and every reload is an exposed scalar-load round trip.
-template <bool PREDICT_NEXT, bool UNIT, typename SecT>
+// (-DSA_STAMP_IIR, diagnostic builds: stamps 3..8 mark the inside of section 2 instead of the FFT passes)
+#ifdef SA_STAMP_IIR
+#define SA_STAMP_SEC(i) do { if constexpr (SIDX == 2) SA_STAMP(i); } while (0)
+#define SA_STAMP_FFT(i) do {} while (0)
+#else
+#define SA_STAMP_SEC(i) do {} while (0)
+#define SA_STAMP_FFT(i) SA_STAMP(i)
+#endif
+template <bool PREDICT_NEXT, bool UNIT, int SIDX, typename SecT>
 __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const SecT &knext, const SecConsts c,
                                             SecConsts &cn, const float4 lanep, float2 *scr_s, int lane, int wave,
                                             v2f &zA, v2f &zB)
 {
+    SA_STAMP_SEC(3);
     // state after both chunks of this thread, from zero state: T = Pc zA + zB
     v2f T = mv_s(c.pc0, c.pc1, zA, zB);
     // inclusive affine scan inside the 16-lane row; levels whose transition power has decayed below
@@ -241,7 +250,9 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     const int row = 4 * wave + (lane >> 4);
     if ((lane & 15) == 15) scr_s[row] = make_float2(T.x, T.y);
     const v2f e = {row_shr<1>(T.x), row_shr<1>(T.y)};            // exclusive: state before this thread, row-local
+    SA_STAMP_SEC(4);
     lds_barrier();
+    SA_STAMP_SEC(5);
     v2f cst;
     if (flags & SA_IIR_SKIP_ROWSCAN) {
         // a row (1024 samples) outlasts the section's memory: the row starts from the previous row's total
@@ -273,6 +284,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
         for (int j = 0; j < 32; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
     }
     const float b0 = c.b0, b1 = c.b1, b2 = c.b2, na1 = -c.a1, na2 = -c.a2;
+    SA_STAMP_SEC(6);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const v2f x = d[j];
@@ -288,6 +300,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
         }
         d[j] = y;
     }
+    SA_STAMP_SEC(7);
     if constexpr (PREDICT_NEXT) {
         cn = load_consts(knext);
         // four accumulators: each chain sees a dependent FMA every fourth instruction
@@ -302,6 +315,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
         zB = nBa + nBb;
         pin_consts(cn);
     }
+    SA_STAMP_SEC(8);
 }
 
 // All NSEC sections run unconditionally (the host pads shorter cascades with identity sections,
@@ -314,7 +328,7 @@ __device__ __forceinline__ void iir_sections(v2f (&d)[32], const PlanT &ka, cons
     if constexpr (S < NSEC) {
         const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
         SecConsts cn = c;
-        iir_section<(S + 1 < NSEC), UNIT>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + 16 * S, lane,
+        iir_section<(S + 1 < NSEC), UNIT, S>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + 16 * S, lane,
                                           wave, zA, zB);
         iir_sections<S + 1, NSEC, UNIT>(d, ka, lt, scr, lane, wave, zA, zB, cn);
     }
@@ -489,7 +503,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     }
 
     // ---- pass A: 32-point FFT over m1 (stride 256), then twiddle W_8192^(k1*m2), m2 = t
-    SA_STAMP(3);
+    SA_STAMP_FFT(3);
     // the thread's twiddle anchors (requested before the butterflies, consumed after them): W^(b t) for
     // b = 1..7 and W^(8 a t) for a = 1..3 with W = W_8192, plus W_16384^(4 t) for the split step.  The 31
     // factors W^(k1 t), k1 = 8a + b, are applied as two complex products per point; the 64 KiB table of all
@@ -509,7 +523,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
             if ((k1 >> 3) != 0) a[k1] = safft::cmul(a[k1], wa[k1 >> 3]);
         }
     }
-    SA_STAMP(4);
+    SA_STAMP_FFT(4);
     // ---- exchange A -> B in two rounds of 16 rows; FFT q of a thread lives in round q:
     //      k1 = 16q + 4 wave + kq, b = lo; inputs ldc[row][16 a + b] with row pitch 272
     cf p[2][16];
@@ -523,7 +537,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 #pragma unroll
         for (int aa = 0; aa < 16; ++aa) p[q][safft::brev(aa, 4)] = ldc[row * 272 + 16 * aa + lo];
     }
-    SA_STAMP(5);
+    SA_STAMP_FFT(5);
     // ---- pass B: 16-point FFT over a, twiddle W_256^(b*c)
     safft::fft_dit<16>(p[0]);
     safft::fft_dit<16>(p[1]);
@@ -537,7 +551,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         p[0][2 * pp + 1] = safft::cmul(p[0][2 * pp + 1], {w.z, w.w});
         p[1][2 * pp + 1] = safft::cmul(p[1][2 * pp + 1], {w.z, w.w});
     }
-    SA_STAMP(6);
+    SA_STAMP_FFT(6);
     // ---- exchange B -> C: a 16x16 transpose inside each 16-lane group, through the row this group
     //      just read (pitch 17).  Only these 16 lanes touch the row: no workgroup barrier; the LDS
     //      executes a wave's accesses in order.
@@ -557,11 +571,11 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    SA_STAMP(7);
+    SA_STAMP_FFT(7);
     // ---- pass C: 16-point FFT over b -> d;  Z[k1 + 32c + 512d], k1 = 16q + 4 wave + kq, c = lo
     safft::fft_dit<16>(p[0]);
     safft::fft_dit<16>(p[1]);
-    SA_STAMP(8);
+    SA_STAMP_FFT(8);
     // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255 (its
     // neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0).  Requested here, through an opaque copy
     // of the thread index: loaded with the other anchors the four registers sit through three FFT passes (and spill in

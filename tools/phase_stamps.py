@@ -26,6 +26,12 @@ NAMES = {"0->1": "stage-in (DMA + chunk read x window)", "1->2": "IIR cascade (6
          "10->11": "split+store round 1", "11->12": "store drain"}
 
 
+# build with `make stamps EXTRA=-DSA_STAMP_IIR`: stamps 3..8 sit inside cascade section 2 (usage: ... 4096 0xA1 iir)
+NAMES_IIR = {"3->4": "sec 2: thread total + in-row scan + row total out", "4->5": "sec 2: LDS barrier",
+             "5->6": "sec 2: row start, start states, DF2T states", "6->7": "sec 2: recursion (32 steps)",
+             "7->8": "sec 2: predictor of section 3 (32 taps)"}
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     mode = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0xA1
@@ -44,8 +50,13 @@ def main():
     s = stamps.cpu().numpy().astype(np.float64)
     iir = mode != 0xB1
     idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12] if iir else [0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+    if len(sys.argv) > 3 and sys.argv[3] == "iir":
+        idx = [3, 4, 5, 6, 7, 8]
+        NAMES.update(NAMES_IIR)
     d = np.diff(s[:, idx], axis=1)
     tot = s[:, 12] - s[:, 0]
+    if idx[0] == 3:
+        tot = s[:, 8] - s[:, 3]
     print(f"B={B} mode=0x{mode:02X}: workgroup lifetime median {np.median(tot):.0f} clk (s_memtime ticks = 100 MHz? see note)")
     labels = [f"{idx[i]}->{idx[i+1]}" for i in range(len(idx) - 1)]
     for i, lab in enumerate(labels):
