@@ -437,3 +437,40 @@ def test_side_stream_and_graph_replay(ch, torch_mod, oracle):
     torch.cuda.synchronize()
     _, _, mag = oracle.chain_fp(x.cpu().numpy(), g["sos"])
     assert rel_maxnorm(out.cpu().numpy(), mag) <= TOL
+
+
+def test_control_plane_refused_during_capture_changes_nothing(ch, torch_mod, oracle):
+    """A control-plane call while the capture of the handle's process call is open is refused (SA_ESTATE) BEFORE it
+    changes anything: host plan, taps in the kernel arguments and device tables stay those of the old filter and window
+    (a half-applied change would pair new taps with old lane matrices: wrong magnitudes, no error)."""
+    from fpga_real_time_fft_analyzer_amd.abi import SpecanError
+    from scipy import signal
+    torch = torch_mod
+    g = load_golden("g2_config1.npz")
+    ch.load_sos(g["sos"])
+    ch.set_filter_mode(0xA1)
+    x = _dev(torch, synth(4, seed=41))
+    ref = ch.process_f32(x).clone()
+    out = torch.empty_like(ref)
+    other = signal.butter(6, 0.4, "highpass", output="sos")
+    graph = torch.cuda.CUDAGraph()
+    refused = []
+    with torch.cuda.graph(graph):
+        ch.process_f32(x, out=out)
+        for call in (lambda: ch.load_sos(other), lambda: ch.set_window_f32(np.blackman(N).astype(np.float32)),
+                     lambda: ch.set_filter_mode(0xB1), lambda: ch.load_coeffs_q7([1] * 12), lambda: ch.set_overlap(2)):
+            try:
+                call()
+                refused.append(False)
+            except SpecanError as e:
+                refused.append(e.code == -4)
+    assert refused == [True] * 5
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert ch.filter_mode == 0xA1 and ch.overlap == 1
+    assert torch.equal(ch.process_f32(x), ref)                       # outside the capture: still the old filter and window
+    ch.load_sos(other)                                               # ... and control-plane calls work again
+    _, _, mag = oracle.chain_fp(x.cpu().numpy(), other)
+    assert rel_maxnorm(ch.process_f32(x).cpu().numpy(), mag) <= TOL
