@@ -308,3 +308,13 @@ def test_fft_regs_host(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fft32" in r.stdout
+
+
+def test_w8_probe_index_model():
+    """The index model of the parked 512-thread kernel (csrc/probes/chain_f32_w8.hip): every exchange, twiddle and the
+    merged radix-2 / split output stage with the kernel's own index formulas, against numpy.fft (tools/w8_model.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "w8_model.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "w8 index model vs numpy.fft" in r.stdout
