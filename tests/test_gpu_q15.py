@@ -143,6 +143,36 @@ def test_zero_tap_uploads_take_the_short_step_and_stay_exact(ch, torch_mod, orac
     assert np.array_equal(up, iq_ref)
 
 
+def test_overlapped_launches_q15(ch, torch_mod, oracle):
+    """sa_set_overlap on the integer path: the FFT of batch k-1 may run under the cascade of batch k (one workspace per
+    launch slot, grown on demand without touching launches in flight).  Bit-exact against the integer model for growing
+    batch sizes, a coefficient upload between overlapped calls, and back in the ordered mode."""
+    torch = torch_mod
+    rng = np.random.default_rng(99)
+    sizes = [3, 17, 5, 64, 33, 2]
+    xs = [rng.integers(-2048, 2048, (b, N)).astype(np.int16) for b in sizes]
+    gui = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
+    ch.set_filter_mode(0x00)
+    ch.set_overlap(2)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        xd = [_dev(torch, x) for x in xs]
+        outs = []
+        for k, x in enumerate(xd):
+            if k == 3:                                       # control plane between overlapped calls: custom coefficients
+                ch.load_coeffs_q7(gui)
+                ch.set_filter_mode(0xA1)
+            outs.append(ch.process_q15(x))
+        ch.flush()
+        got = [o.cpu().numpy() for o in outs]
+    s.synchronize()
+    for k, x in enumerate(xs):
+        ref = oracle.chain_q15(x, None, 0, 0x00 if k < 3 else 0xA1, None if k < 3 else gui, None)
+        assert np.array_equal(got[k], ref), k
+    ch.set_overlap(1)
+    assert np.array_equal(ch.process_q15(_dev(torch, xs[3])).cpu().numpy(), got[3])
+
+
 def test_random_wide_cascades(ch, torch_mod, oracle):
     """Wide mode (0xA2): random Q2.14 cascades of 1..6 sections, any int16 tap (saturating accumulators make
     unstable ones well defined), both window modes, bit-exact against the integer model."""
