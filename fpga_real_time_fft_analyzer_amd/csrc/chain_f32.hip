@@ -251,7 +251,11 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     if ((lane & 15) == 15) scr_s[row] = make_float2(T.x, T.y);
     const v2f e = {row_shr<1>(T.x), row_shr<1>(T.y)};            // exclusive: state before this thread, row-local
     SA_STAMP_SEC(4);
+#ifdef SA_AB_NO_SCAN_BARRIER          // timing probe only (results invalid): what the six scan barriers of a frame cost at most
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     lds_barrier();
+#endif
     SA_STAMP_SEC(5);
     v2f cst;
     if (flags & SA_IIR_SKIP_ROWSCAN) {
