@@ -126,8 +126,15 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         // DMA (vmcnt) and, before overwriting the rows with round 1, for its own reads of round 0 (lgkmcnt).
         // Three barriers fewer per frame; a wave delayed on its SIMD no longer holds the other three here.
         if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_chunk_half(xin, h, smem, lane, wave);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SA_AB_PROBE == 1                    // timing probes (results invalid), profiles/r3_timing_probes.txt: round 1 of the stage-in skipped
+        if (h == 0)
+#elif SA_AB_PROBE == 6                  // probe 6: no input traffic at all
+        if (false)
+#endif
+        {
+            dma_chunk_half(xin, h, smem, lane, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         // nothing of the window arithmetic below may be scheduled above the wait (register-only instructions do
         // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
         __builtin_amdgcn_sched_barrier(0);
@@ -450,7 +457,9 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         v2f d[32];
         stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
         SA_STAMP(1);
+#if SA_AB_PROBE != 3                    // probe 3: the whole cascade skipped (window -> FFT)
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
+#endif
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
         // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
@@ -516,7 +525,9 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     float4 an[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) an[i] = twT[i * 256 + t];
+#if SA_AB_PROBE != 4
     safft::fft_dit<32>(a);
+#endif
     {
         const cf wb[8] = {{1.f, 0.f}, {an[0].x, an[0].y}, {an[0].z, an[0].w}, {an[1].x, an[1].y},
                           {an[1].z, an[1].w}, {an[2].x, an[2].y}, {an[2].z, an[2].w}, {an[3].x, an[3].y}};
@@ -543,8 +554,12 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     }
     SA_STAMP_FFT(5);
     // ---- pass B: 16-point FFT over a, twiddle W_256^(b*c)
+#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[0]);
+#endif
+#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[1]);
+#endif
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {                       // twB4[pp][b] = (W_256^(2pp * b), W_256^((2pp+1) * b))
         const float4 w = twB[pp * 16 + lo];
@@ -577,8 +592,12 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     }
     SA_STAMP_FFT(7);
     // ---- pass C: 16-point FFT over b -> d;  Z[k1 + 32c + 512d], k1 = 16q + 4 wave + kq, c = lo
+#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[0]);
+#endif
+#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[1]);
+#endif
     SA_STAMP_FFT(8);
     // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255 (its
     // neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0).  Requested here, through an opaque copy
