@@ -436,13 +436,14 @@ def main():
         # --pmc passes over this same kernel and batch (profiles/, tools/pmc_profile.sh).  Counters cannot be
         # read inside the timed process, so this is a constant quoted from that profile -- `traffic_source`
         # says which -- and null when the profile was taken at another batch size.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_busy = None, None, None
         for name in ("r3_pmc_traffic.json",):        # regenerated with the round's kernel (tools/pmc_profile.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pj = json.load(fh)
                 if pj.get("batch") == B:
                     traffic, traffic_src = pj["traffic_bytes_per_launch"], f"profiles/{name}"
+                    valu_busy = pj.get("valu_busy_frac")
                     break
             except (OSError, ValueError, KeyError):
                 continue
@@ -482,7 +483,10 @@ def main():
                                           else "per-launch HIP events on the launch stream"),
                                 "kernel": wl.kernel_name, "kernel_ms_avg": round(k_avg_ms, 4),
                                 "kernel_ms_median": round(k_med_ms, 4),
-                                "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32}
+                                "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32,
+                                # the second ceiling: share of an ordered launch a SIMD's vector pipe is
+                                # executing, from the same committed counter passes as `traffic` (quoted, not live)
+                                "secondary": {"bound": "valu_fp32", "busy_frac": valu_busy, "source": traffic_src}}
             line["ordered"] = {"value": round(fps_ord, 1), "ms_per_step": round(elapsed_ord / a.steps * 1e3, 4),
                                "kernel_ms_avg": round(k_avg_ms, 4), "achieved": round(achieved_ord, 1),
                                "frac": round(achieved_ord / HBM_PEAK_GBS, 4),
