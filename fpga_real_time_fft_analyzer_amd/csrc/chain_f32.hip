@@ -51,6 +51,14 @@ __device__ __forceinline__ v2f mv_v(const v2f c0, const v2f c1, const v2f v, con
         : "=&v"(r) : "v"(c0), "v"(c1), "v"(v), "v"(add));
     return r;
 }
+__device__ __forceinline__ v2f mv0_s(const v2f c0, const v2f c1, const v2f v)          // c0 * v.x + c1 * v.y
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(r) : "s"(c0), "s"(c1), "v"(v));
+    return r;
+}
 __device__ __forceinline__ void mv_acc_s(v2f &z, const v2f c0, const v2f c1, const v2f v)
 {
     asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
@@ -206,6 +214,34 @@ __device__ __forceinline__ void tap_fma8(v2f &nAa, v2f &nBa, v2f &nAb, v2f &nBb,
 #undef SA_TAP
 }
 
+// The predictor of one section over the thread's 32 fresh pairs y = (chunk A, chunk B): chunk end states from zero state,
+//   z = A^16 (sum_{j<16} m[j] y[j]) + sum_{j<16} m[j] y[16 + j]     (SaIirSecK::mnext; block Horner over two half chunks:
+// the same sixteen tap pairs serve both halves and stay in their scalar registers).
+__device__ __forceinline__ void predict_chunk_ends(const v2f (&tp)[16], const v2f q0, const v2f q1, const v2f (&d)[32],
+                                                   v2f &zA, v2f &zB)
+{
+    // four accumulators: each chain sees a dependent FMA every fourth instruction
+    v2f nAa = {0.f, 0.f}, nBa = {0.f, 0.f}, nAb = {0.f, 0.f}, nBb = {0.f, 0.f};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 16; j += 8) {
+            const v2f t8[8] = {tp[j], tp[j + 1], tp[j + 2], tp[j + 3], tp[j + 4], tp[j + 5], tp[j + 6], tp[j + 7]};
+            const int o = 16 * hh + j;
+            const v2f y8[8] = {d[o], d[o + 1], d[o + 2], d[o + 3], d[o + 4], d[o + 5], d[o + 6], d[o + 7]};
+            tap_fma8(nAa, nBa, nAb, nBb, t8, y8);
+        }
+        if (hh == 0) {
+            nAa = mv0_s(q0, q1, nAa + nAb);
+            nBa = mv0_s(q0, q1, nBa + nBb);
+            nAb = v2f{0.f, 0.f};
+            nBb = v2f{0.f, 0.f};
+        }
+    }
+    zA = nAa + nAb;
+    zB = nBa + nBb;
+}
+
 // The wave-uniform constants of one section, read one section ahead (while the previous section's loops run)
 // so that their scalar-load latency is not on the path between two sections.
 struct SecConsts {
@@ -228,9 +264,8 @@ __device__ __forceinline__ void pin_consts(const SecConsts &c)
 //   zA, zB (out): the same for the NEXT section
 //   c  (in)    : this section's constants;   cn (out): the next section's, requested here
 // Two loops: the recursion (3 scalar constants), then the next section's predictor over the fresh outputs (its
-// 32 tap pairs, requested before the recursion so that they arrive under it).  Fused into one loop the 64 tap
-// registers are live from the top of the section and, with the section constants, exceed the 102 SGPRs a wave
-// has: the compiler then reloads them piecemeal, and every reload is an exposed scalar-load round trip.
+// 16 tap pairs and half-chunk matrix, requested before the recursion so that they arrive under it and resident in
+// 36 scalar registers until the predictor is done: predict_chunk_ends).
 // (-DSA_STAMP_IIR, diagnostic builds: stamps 3..8 mark the inside of section 2 instead of the FFT passes)
 #ifdef SA_STAMP_IIR
 #define SA_STAMP_SEC(i) do { if constexpr (SIDX == 2) SA_STAMP(i); } while (0)
@@ -289,10 +324,12 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     const v2f q1 = {aS.x, bS.x}, q2 = {aS.y, bS.y};
     v2f s1 = c.mb0.x * q1 + c.mb1.x * q2, s2 = c.mb0.y * q1 + c.mb1.y * q2;
     // the next section's tap pairs: requested now, consumed after the recursion
-    v2f tp[32];
+    v2f tp[16], h0 = {0.f, 0.f}, h1 = {0.f, 0.f};
     if constexpr (PREDICT_NEXT) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
+        for (int j = 0; j < 16; ++j) tp[j] = v2f{k.mnext[j][0], k.mnext[j][1]};
+        h0 = v2f{k.p16next[0], k.p16next[1]};
+        h1 = v2f{k.p16next[2], k.p16next[3]};
     }
     const float b0 = c.b0, b1 = c.b1, b2 = c.b2, na1 = -c.a1, na2 = -c.a2;
     SA_STAMP_SEC(6);
@@ -314,16 +351,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     SA_STAMP_SEC(7);
     if constexpr (PREDICT_NEXT) {
         cn = load_consts(knext);
-        // four accumulators: each chain sees a dependent FMA every fourth instruction
-        v2f nAa = {0.f, 0.f}, nBa = {0.f, 0.f}, nAb = {0.f, 0.f}, nBb = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 32; j += 8) {
-            const v2f t8[8] = {tp[j], tp[j + 1], tp[j + 2], tp[j + 3], tp[j + 4], tp[j + 5], tp[j + 6], tp[j + 7]};
-            const v2f y8[8] = {d[j], d[j + 1], d[j + 2], d[j + 3], d[j + 4], d[j + 5], d[j + 6], d[j + 7]};
-            tap_fma8(nAa, nBa, nAb, nBb, t8, y8);
-        }
-        zA = nAa + nAb;
-        zB = nBa + nBb;
+        predict_chunk_ends(tp, h0, h1, d, zA, zB);
         pin_consts(cn);
     }
     SA_STAMP_SEC(8);
@@ -351,18 +379,11 @@ __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const
 {
     // predictor for the first section (later ones run after the previous section's recursion)
     const SecConsts c0 = load_consts(ka.sec[0]);
-    v2f nAa = {0.f, 0.f}, nBa = {0.f, 0.f}, nAb = {0.f, 0.f}, nBb = {0.f, 0.f};
+    v2f tp[16];
 #pragma unroll
-    for (int j = 0; j < 32; j += 8) {
-        v2f t8[8], y8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            t8[e] = v2f{ka.m0[j + e][0], ka.m0[j + e][1]};
-            y8[e] = d[j + e];
-        }
-        tap_fma8(nAa, nBa, nAb, nBb, t8, y8);
-    }
-    v2f zA = nAa + nAb, zB = nBa + nBb;
+    for (int j = 0; j < 16; ++j) tp[j] = v2f{ka.m0[j][0], ka.m0[j][1]};
+    v2f zA, zB;
+    predict_chunk_ends(tp, v2f{ka.p16_0[0], ka.p16_0[1]}, v2f{ka.p16_0[2], ka.p16_0[3]}, d, zA, zB);
     pin_consts(c0);
     iir_sections<0, NSEC, UNIT>(d, ka, lt, scr, t & 63, t >> 6, zA, zB, c0);
 }

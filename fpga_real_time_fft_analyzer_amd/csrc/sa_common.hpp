@@ -28,11 +28,17 @@
 // the float32 scan then loses up to 30x against a sequential evaluation (measured).
 // mback = T^-1 (row-major) takes the two start states back to DF2T right before the recursion.  It is the
 // identity for first-order, repeated-pole and padding sections.
+#define SA_PRED_TAPS 16    // predictor taps per half chunk (block Horner, below)
 struct SaIirSecK {
-    float mnext[SA_CHUNK][2];  // predictor taps (m1, m2) of the NEXT section (zero for the last one): its chunk end
-                               // states from zero state are accumulated while this section's outputs appear.
-                               // They sit in front of this section's own constants so that everything a section
-                               // needs is one contiguous run of scalar loads from the kernel-argument segment.
+    // Predictor of the NEXT section (zeros for the last one): its chunk end state from zero state,
+    //     z = sum_{j<32} A^(31-j) Bv y[j]  =  A^16 (sum_{j<16} m[j] y[j]) + sum_{j<16} m[j] y[16+j],   m[j] = A^(15-j) Bv,
+    // accumulated while this section's outputs appear.  Sixteen tap pairs and one matrix (36 scalar registers) stay
+    // resident across the recursion; all 32 tap pairs (64 registers) did not fit beside the section's other constants
+    // and the compiler re-fetched half of them piecemeal, each fetch an exposed scalar-load round trip.
+    // They sit in front of this section's own constants so that everything a section needs is one contiguous run
+    // of scalar loads from the kernel-argument segment.
+    float mnext[SA_PRED_TAPS][2];
+    float p16next[4];      // A^16 of the next section, column-major
     float c[5];            // b0,b1,b2,a1,a2
     int flags;
     float pad[2];
@@ -42,6 +48,7 @@ struct SaIirSecK {
     float mback[4];        // T^-1
     float plev[4][4];      // P2^(1,2,4,8)      in-row scan (DPP row_shr 1,2,4,8)
     float prow[4][4];      // Prow^(1,2,4,8)    scan over the 16 rows of a frame
+    float pad2[12];        // 96 floats: a whole number of 64-byte scalar-cache lines per section
 };
 
 struct SaIirK {
@@ -51,7 +58,8 @@ struct SaIirK {
     float gain;            // the folded cascade gain (1 when unit == 0); informational for tests
     int wingen;            // 1: the window is a0 - a1 cos(2 pi n / (N-1)) and the IIR kernels evaluate it in place
                            //    (SaIirLaneTab::wgen / wcs / wg0); 0: they read the table win_t
-    float m0[SA_CHUNK][2]; // predictor taps of section 0: chunk end state from zero state = sum_j m0[j] x[j]
+    float m0[SA_PRED_TAPS][2]; // predictor of section 0 (SaIirSecK::mnext): taps A^(15-j) Bv ...
+    float p16_0[4];            // ... and A^16, column-major
     SaIirSecK sec[SA_MAXSEC];
 };
 

@@ -256,12 +256,13 @@ void build_plan(const double *sos_in, int nsec_in, SaIirK *plan, SaIirLaneTab *l
         double v0 = T.a * (b1 - a1 * b0) + T.b * (b2 - a2 * b0);      // T Bv
         double v1 = T.c * (b1 - a1 * b0) + T.d * (b2 - a2 * b0);
         float (*mdst)[2] = s == 0 ? plan->m0 : plan->sec[s - 1].mnext;       // taps of section s ride with section s-1
-        for (int j = SA_CHUNK - 1; j >= 0; --j) {         // m[j] = A^(31-j) Bv
+        for (int j = SA_PRED_TAPS - 1; j >= 0; --j) {     // m[j] = A^(15-j) Bv: the taps of a HALF chunk (block Horner)
             mdst[j][0] = (float)v0;
             mdst[j][1] = (float)v1;
             const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
             v0 = n0; v1 = n1;
         }
+        put_cm(s == 0 ? plan->p16_0 : plan->sec[s - 1].p16next, mpow(A, SA_PRED_TAPS));
         const Mat2 Pc = mpow(A, SA_CHUNK);                  // one chunk
         const Mat2 P2 = mul(Pc, Pc);                        // one thread (two chunks)
         const Mat2 Prow = mpow(P2, 16);                     // one 16-lane row
@@ -637,7 +638,8 @@ int set_window_f32_from(sa_handle *h, const float *w)
 }
 
 // flat float view for tests (layout documented in include/specan.h, sa_iir_plan_from_sos): header, the six
-// sections' constants, then the predictor taps m[6][32][2] and the per-lane matrices p[6][16][4]
+// sections' constants, then the predictor taps m[6][16][2], their half-chunk matrices p16[6][4] and the per-lane
+// matrices p[6][16][4] (every matrix row-major here)
 int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
 {
     std::vector<float> v;
@@ -655,7 +657,11 @@ int export_plan(const SaIirK &p, const SaIirLaneTab &lt, float *out, int cap)
     }
     for (int s = 0; s < SA_MAXSEC; ++s) {
         const float (*m)[2] = s == 0 ? p.m0 : p.sec[s - 1].mnext;
-        v.insert(v.end(), &m[0][0], &m[0][0] + 2 * SA_CHUNK);
+        v.insert(v.end(), &m[0][0], &m[0][0] + 2 * SA_PRED_TAPS);
+    }
+    for (int s = 0; s < SA_MAXSEC; ++s) {
+        const float *m = s == 0 ? p.p16_0 : p.sec[s - 1].p16next;
+        v.push_back(m[0]); v.push_back(m[2]); v.push_back(m[1]); v.push_back(m[3]);
     }
     for (int sct = 0; sct < SA_MAXSEC; ++sct)
         for (int i = 0; i < 16; ++i) {

@@ -123,8 +123,9 @@ def test_pack_frame_is_little_endian(hip_lib_built):
 # ---- IIR plan algebra: emulate the kernel's predict / scan / recurse in float32 on the CPU
 def _parse_plan(plan):
     """Flat view written by sa_iir_plan_from_sos: SaIirK (nsec, unit, gain, pad, 6 x {c[8], pc[4], mback[4],
-    plev[4][4], prow[4][4]}) followed by SaIirLaneTab {m[6][32][2], p[6][16][4]}.  Taps and matrices are in
-    the section's pole coordinates; mback takes a state back to DF2T."""
+    plev[4][4], prow[4][4]}) followed by the predictor taps m[6][16][2], their half-chunk matrices p16[6][4] (A^16) and
+    SaIirLaneTab's p[6][16][4].  Taps and matrices are in the section's pole coordinates; mback takes a state back to
+    DF2T."""
     nsec = int(plan[:1].view(np.int32)[0])
     unit = int(plan[1:2].view(np.int32)[0])
     gain = float(plan[2]) if unit else 1.0
@@ -136,9 +137,10 @@ def _parse_plan(plan):
         plev = plan[off:off + 16].reshape(4, 4); off += 16
         prow = plan[off:off + 16].reshape(4, 4); off += 16
         secs.append([c, pc, plev, prow, None, mback])
-    mt = plan[off:off + 6 * 64].reshape(6, 32, 2); off += 6 * 64
+    mt = plan[off:off + 6 * 32].reshape(6, 16, 2); off += 6 * 32
+    p16 = plan[off:off + 6 * 4].reshape(6, 4); off += 6 * 4
     for i in range(6):
-        secs[i][4] = mt[i]
+        secs[i][4] = (mt[i], p16[i])
     lt = plan[off:off + 6 * 64].reshape(6, 16, 4); off += 6 * 64
     assert off == plan.size
     return nsec, secs, lt, np.float32(gain)
@@ -165,10 +167,14 @@ def emulate_chunked_iir(plan, x):
     v = (x.astype(f) * gain).astype(f).reshape(256, 2, 32).copy()   # unit form: cascade gain folded into the window              # [thread][chunk][j]
     for s in range(nsec):
         c, pc, plev, prow, m, mb = secs[s]
+        m, p16 = m
         z = np.zeros((256, 2, 2), f)                         # [thread][chunk][state]
-        for j in range(32):
-            z[:, :, 0] += m[j, 0] * v[:, :, j]
-            z[:, :, 1] += m[j, 1] * v[:, :, j]
+        for hh in range(2):                                  # block Horner over the two half chunks (predict_chunk_ends)
+            for j in range(16):
+                z[:, :, 0] += m[j, 0] * v[:, :, 16 * hh + j]
+                z[:, :, 1] += m[j, 1] * v[:, :, 16 * hh + j]
+            if hh == 0:
+                z = np.stack([p16[0] * z[..., 0] + p16[1] * z[..., 1], p16[2] * z[..., 0] + p16[3] * z[..., 1]], axis=-1).astype(f)
         zA, zB = z[:, 0, :], z[:, 1, :]
         zT = np.stack([pc[0] * zA[:, 0] + pc[1] * zA[:, 1] + zB[:, 0],
                        pc[2] * zA[:, 0] + pc[3] * zA[:, 1] + zB[:, 1]], axis=-1).astype(f)
@@ -228,7 +234,7 @@ def test_iir_plan_reproduces_sosfilt(hip_lib_built, oracle):
     g = load_golden("g3_fp32_frames.npz")
     sos = g["sos"]
     plan = iir_plan_from_sos(sos)
-    assert plan.size == 4 + 6 * (8 + 4 + 4 + 16 + 16 + 64) + 6 * 16 * 4
+    assert plan.size == 4 + 6 * (8 + 4 + 4 + 16 + 16 + 32 + 4) + 6 * 16 * 4
     hann = oracle.hann_f64()
     for i in range(2):
         xw = (g["x"][i].astype(np.float64) * hann).astype(np.float32)
