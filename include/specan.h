@@ -26,6 +26,10 @@
  *     (a window or coefficient upload may block the HOST briefly when more than four uploads are
  *     still waiting for their copies; a Q15 workspace that is outgrown is kept until sa_destroy()
  *     rather than freed, because hipFree synchronises the device).
+ *   - device: a handle belongs to the GPU given to sa_create().  Every call that touches the GPU makes that
+ *     device the calling thread's current HIP device (hipSetDevice) and leaves it so; the stream and the
+ *     pointers passed to a process call must belong to it (not checked: a check costs more than a launch).
+ *     One process per GPU (torch.distributed ranks) or one host thread per GPU both work.
  *   - stream lifetime: the library uses the stream passed to a process call only inside that call.
  *     The caller may destroy it afterwards, in any order with later calls and sa_destroy(): uploads,
  *     stream switches and sa_destroy() order themselves behind an event the handle owns, bound to
