@@ -217,6 +217,13 @@ class SpectrumChain:
         self._check(self._lib.sa_get_overlap(self._h, C.byref(v)))
         return v.value
 
+    def overlap_streams_side_by_side(self) -> bool:
+        """Tests: re-run the library's probe on the handle's internal streams and the current stream
+        (sa_debug_overlap_streams)."""
+        v = C.c_int()
+        self._check(self._lib.sa_debug_overlap_streams(self._h, self._stream(), C.byref(v)))
+        return bool(v.value)
+
     def flush(self):
         """Make the current stream wait for every outstanding overlapped call (no host wait)."""
         self._check(self._lib.sa_flush(self._h, self._stream()))

@@ -380,6 +380,8 @@ struct sa_handle {
     // streams so that the tail of one launch runs under the head of the next; see include/specan.h
     int overlap = 1;
     hipStream_t ov_stream[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t ov_fit_stream = nullptr;      // the caller stream the internal streams were last fitted to (compared, never used)
+    bool ov_fit_valid = false;
     hipEvent_t ov_fork[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ov_done[kMaxOverlap] = {nullptr, nullptr, nullptr, nullptr};
     bool ov_used[kMaxOverlap] = {false, false, false, false};      // ov_done[i] has been recorded
@@ -413,6 +415,74 @@ int fail(sa_handle *h, int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e_ = (call);                                  \
         if (e_ != hipSuccess) return fail((h), SA_EHIP, #call, e_); \
     } while (0)
+
+// ---- overlap mode: which streams run beside each other ------------------------------------------------------
+// The runtime maps a process's streams onto a few hardware queues (four here) and two streams that share a queue
+// execute in order: a handle whose two internal streams fall on one queue gets no overlap and pays for the fork /
+// join events on top (measured, tools/ubench/stream_pairs.hip and profiles/r3_overlap_streams.txt: streams 3 and 4
+// created back to back share a queue; such a handle ran 144 us per batch against 135 us stream-ordered and 127 us
+// with two queues).  The mapping is not exposed, so sa_set_overlap() asks the hardware: a one-wave kernel that
+// waits 100 us on the constant 100 MHz counter is put on both streams; if the second finishes within 150 us of the
+// first one's start they ran side by side.  The loop ends on the counter or on its iteration cap, whichever first.
+__global__ void sa_spin_kernel(unsigned ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 200000 && __builtin_amdgcn_s_memrealtime() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(8);
+}
+
+// 1 = kernels on a and b overlap, 0 = they run one after the other, negative = HIP error (text in *err)
+int streams_run_side_by_side(hipStream_t a, hipStream_t b, hipError_t *err)
+{
+    constexpr unsigned kTicks = 10000;                   // 100 us
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&ea);
+    if (e == hipSuccess) e = hipEventCreate(&eb);
+    float ms = 1e9f;
+    for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {        // pass 0 warms the launch path up (code object load)
+        const unsigned ticks = pass == 0 ? 10u : kTicks;
+        e = hipEventRecord(e0, a);
+        if (e == hipSuccess) hipLaunchKernelGGL(sa_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+        if (e == hipSuccess) hipLaunchKernelGGL(sa_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ea, a);
+        if (e == hipSuccess) e = hipEventRecord(eb, b);
+        if (e == hipSuccess) e = hipEventSynchronize(ea);
+        if (e == hipSuccess) e = hipEventSynchronize(eb);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, eb);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    if (e != hipSuccess) { *err = e; return -1; }
+    return ms < 0.15f ? 1 : 0;
+}
+
+// A new stream that runs beside every stream in `avoid`.  Best effort: after six candidates the last one is kept
+// whatever the probe said (a GPU busy with other work can make side-by-side kernels look serial, and with four
+// hardware queues five streams cannot all be apart).
+int pick_stream(sa_handle *h, const hipStream_t *avoid, int navoid, hipStream_t *out)
+{
+    hipStream_t rejected[6];
+    int nrej = 0, rc = SA_OK;
+    *out = nullptr;
+    for (int tries = 0; tries < 6 && !*out && rc == SA_OK; ++tries) {
+        hipStream_t c = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = fail(h, SA_EHIP, "overlap: hipStreamCreateWithFlags", e); break; }
+        bool ok = true;
+        for (int j = 0; j < navoid && ok; ++j) {
+            hipError_t pe = hipSuccess;
+            const int r = streams_run_side_by_side(avoid[j], c, &pe);
+            if (r < 0) { rc = fail(h, SA_EHIP, "overlap: stream probe", pe); ok = false; }
+            else ok = r == 1;
+        }
+        if (rc == SA_OK && (ok || tries == 5)) *out = c;
+        else rejected[nrej++] = c;
+    }
+    for (int q = 0; q < nrej; ++q) (void)hipStreamDestroy(rejected[q]);
+    return rc;
+}
 
 constexpr size_t kStageBytes = sizeof(SaIirLaneTab8) > sizeof(SaIirLaneTab) ? sizeof(SaIirLaneTab8) : sizeof(SaIirLaneTab);
 // (the probe kernels' table is the larger one; sized for it in every build so that the staging ring does not change)
@@ -471,6 +541,36 @@ struct CallCtx {
     bool overlapped, captured;
 };
 
+// First overlapped call from a caller stream: an internal stream that shares a hardware queue with the CALLER's
+// stream is as bad as two internal streams on one queue (the join waits of the caller's stream sit in front of
+// the internal stream's next kernel: the six-handle run of profiles/r3_overlap_streams.txt), and the caller's
+// stream is only known here.  Every internal stream is probed against it and replaced if they run in order.
+// Costs a host wait for the caller stream's earlier work plus ~0.3 ms per internal stream, once per (handle,
+// caller stream).
+int fit_overlap_streams(sa_handle *h, hipStream_t user)
+{
+    for (int i = 0; i < h->overlap; ++i) {
+        hipError_t pe = hipSuccess;
+        const int r = streams_run_side_by_side(user, h->ov_stream[i], &pe);
+        if (r < 0) return fail(h, SA_EHIP, "overlap: stream probe", pe);
+        if (r == 1) continue;
+        hipStream_t avoid[sa_handle::kMaxOverlap + 1] = {user};
+        int n = 1;
+        for (int j = 0; j < h->overlap; ++j)
+            if (j != i) avoid[n++] = h->ov_stream[j];
+        hipStream_t repl = nullptr;
+        const int rc = pick_stream(h, avoid, n, &repl);
+        if (rc != SA_OK) return rc;
+        if (h->ov_used[i]) SA_HIP(h, hipEventSynchronize(h->ov_done[i]));      // the old stream's work is over
+        (void)hipStreamDestroy(h->ov_stream[i]);
+        h->ov_stream[i] = repl;
+        h->ov_seen_gen[i] = h->upload_gen - 1;                                   // the new stream has seen no upload
+    }
+    h->ov_fit_stream = user;
+    h->ov_fit_valid = true;
+    return SA_OK;
+}
+
 int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
 {
     c->stream = user;
@@ -482,6 +582,10 @@ int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
     if (h->overlap > 1) {
         if (c->captured)
             return fail(h, SA_ESTATE, "overlapped launches (sa_set_overlap > 1) cannot be captured into a graph");
+        if (!h->ov_fit_valid || h->ov_fit_stream != user) {
+            const int rc = fit_overlap_streams(h, user);
+            if (rc != SA_OK) return rc;
+        }
         const int d = h->overlap, slot = (int)(h->ov_calls % (unsigned)d);
         SA_HIP(h, hipEventRecord(h->ov_fork[slot], user));
         // join: the call issued d-1 calls ago (the next user of the oldest slot is the call after this one)
@@ -942,7 +1046,10 @@ int sa_set_overlap(sa_handle *h, int depth)
         h->ov_unjoined[i] = false;
     }
     for (int i = 0; i < depth; ++i) {
-if (!h->ov_stream[i]) SA_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[i], hipStreamNonBlocking));
+        if (!h->ov_stream[i]) {
+            const int rc = pick_stream(h, h->ov_stream, i, &h->ov_stream[i]);     // beside the streams the handle already has
+            if (rc != SA_OK) return rc;
+        }
         if (!h->ov_fork[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_fork[i], hipEventDisableTiming));
         if (!h->ov_done[i]) SA_HIP(h, hipEventCreateWithFlags(&h->ov_done[i], hipEventDisableTiming));
         // every slot starts with the workspace the handle already has somewhere
@@ -953,6 +1060,7 @@ if (!h->ov_stream[i]) SA_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[i], hipSt
     }
     h->overlap = depth;
     h->ov_calls = 0;
+    h->ov_fit_valid = false;
     return SA_OK;
 }
 
@@ -960,6 +1068,23 @@ int sa_get_overlap(const sa_handle *h, int *depth)
 {
     if (!h || !depth) return SA_EINVAL;
     *depth = h->overlap;
+    return SA_OK;
+}
+
+int sa_debug_overlap_streams(sa_handle *h, void *stream, int *side_by_side)
+{
+    if (!h || !side_by_side) return SA_EINVAL;
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
+    SA_HIP(h, hipSetDevice(h->device));
+    *side_by_side = 1;
+    if (h->overlap < 2) return SA_OK;
+    for (int i = 0; i < h->overlap; ++i)
+        for (int j = -1; j < i; ++j) {                       // j = -1: the caller's stream
+            hipError_t pe = hipSuccess;
+            const int r = streams_run_side_by_side(j < 0 ? (hipStream_t)stream : h->ov_stream[j], h->ov_stream[i], &pe);
+            if (r < 0) return fail(h, SA_EHIP, "sa_debug_overlap_streams", pe);
+            if (r == 0) *side_by_side = 0;
+        }
     return SA_OK;
 }
 

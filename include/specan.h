@@ -117,9 +117,18 @@ int sa_reserve(sa_handle *h, int max_batch);
  *   - process calls cannot be captured into a hipGraph (SA_ESTATE);
  *   - control-plane calls stay stream-ordered: they apply to all later calls and to no earlier one.
  * depth = 1 (the default) is the strictly stream-ordered mode described above.  sa_set_overlap()
- * waits on the host for the handle's own outstanding work when the depth changes. */
+ * waits on the host for the handle's own outstanding work when the depth changes.
+ * The internal streams are chosen so that they execute side by side with each other AND with the caller's stream:
+ * the runtime maps streams onto a few hardware queues and two streams on one queue run in order (a handle with
+ * such a pair was slower in overlap mode than without it).  The mapping is not exposed, so the library probes
+ * candidate streams with a 100 us one-wave kernel: in sa_set_overlap() among themselves, and in the FIRST
+ * overlapped process call made from a given caller stream against that stream -- that one call waits on the host
+ * for the stream's earlier work and takes about a millisecond longer.  Best effort on a GPU busy with other work. */
 int sa_set_overlap(sa_handle *h, int depth /* 1..4 */);
 int sa_get_overlap(const sa_handle *h, int *depth);
+/* Introspection for tests: re-runs that probe on the handle's internal streams and `stream`;
+ * *side_by_side = 1 if every pair overlaps. */
+int sa_debug_overlap_streams(sa_handle *h, void *stream, int *side_by_side);
 /* Make `stream` wait for every outstanding overlapped call of the handle (no host wait). */
 int sa_flush(sa_handle *h, void *stream);
 

@@ -296,6 +296,35 @@ def test_overlapped_launches_contract(ch, torch_mod, oracle, depth):
     assert torch.equal(ch.process_f32(xs[0]), ref[0])
 
 
+def test_overlap_streams_are_picked_to_run_side_by_side(chain_cls, torch_mod):
+    """The runtime maps streams onto four hardware queues and two streams on one queue run in order (tools/ubench/
+    stream_pairs.hip): a handle whose internal streams shared a queue lost instead of gained in overlap mode.
+    The library probes for streams that do overlap -- among themselves in sa_set_overlap, against the caller's stream
+    in the first overlapped call; here ten handles are created with foreign streams in between (which moves the
+    mapping along) and every one of them must end up with streams that run beside each other and the caller's."""
+    keep, foreign = [], []
+    x = torch_mod.zeros((4, N), dtype=torch_mod.float32, device="cuda")
+    for i in range(10):
+        foreign += [torch_mod.cuda.Stream() for _ in range(i % 3)]
+        c = chain_cls(0)
+        c.set_overlap(2 if i % 4 else 3)
+        c.process_f32(x)                      # the first overlapped call fits the streams to the caller's stream
+        c.flush()
+        keep.append(c)
+    torch_mod.cuda.synchronize()
+    assert all(c.overlap_streams_side_by_side() for c in keep)
+    # ... and to another caller stream when the calls move there
+    side = torch_mod.cuda.Stream()
+    with torch_mod.cuda.stream(side):
+        for c in keep[:4]:
+            c.process_f32(x)
+            c.flush()
+        side.synchronize()
+        assert all(c.overlap_streams_side_by_side() for c in keep[:4])
+    for c in keep:
+        c.close()
+
+
 def test_edge_inputs(ch, torch_mod):
     g = load_golden("g2_config1.npz")
     ch.load_sos(g["sos"])

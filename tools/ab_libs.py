@@ -52,6 +52,8 @@ for name in sys.argv[1:]:
         L.sa_flush.argtypes = [C.c_void_p, C.c_void_p]
         assert L.sa_set_overlap(h, depth) == 0
         name = f"{name}@ov{depth}"
+    if any(nm == name for nm, _, _ in libs):
+        name = f"{name}#{len(libs)}"            # the same build on a further handle
     libs.append((name, L, h))
 st = torch.cuda.current_stream().cuda_stream
 ROUNDS, REPS = 12, 40
