@@ -325,8 +325,8 @@ class GpuWorkload:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--buffers", type=int, default=4,
                     help="input/output buffer pairs used round-robin (one pair of 256 MiB + 256 MiB would stay in "
