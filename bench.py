@@ -322,6 +322,42 @@ class GpuWorkload:
         self.ch.close()
 
 
+def power_sample(wl, dev_index, seconds):
+    """Socket power and shader clock of the card while wl.step() runs back to back for `seconds` (untimed)."""
+    import subprocess
+    import threading
+    shots, stop = [], threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showpower", "--showclocks", "--showmaxpower",
+                                    "--json"], capture_output=True, text=True, timeout=10)
+                card = next(iter(json.loads(r.stdout).values()))
+                shots.append((float(card["Current Socket Graphics Package Power (W)"]),
+                              float(card["Max Graphics Package Power (W)"]),
+                              float(card["sclk clock speed:"].strip("()").lower().replace("mhz", ""))))
+            except Exception:                                          # noqa: BLE001  (tool missing, other layout)
+                return
+            stop.wait(0.2)
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            wl.step()
+        wl.sync()
+    stop.set()
+    th.join(timeout=15)
+    shots = shots[2:] if len(shots) > 4 else shots                     # the first readings still average the ramp-up
+    if not shots:
+        return None
+    w = sorted(x[0] for x in shots)
+    f = sorted(x[2] for x in shots)
+    return {"socket_w": w[len(w) // 2], "cap_w": shots[0][1], "sclk_mhz": f[len(f) // 2], "samples": len(shots),
+            "source": "rocm-smi during an untimed repeat of the headline step loop"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +371,7 @@ def main():
                     help="launches of the handle kept in flight in the timed region (sa_set_overlap; 1 = strictly "
                          "stream-ordered, which is also measured and reported under 'ordered')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     ap.add_argument("--extras", action="store_true", help="also time the bypass (config 2) and Q15 (config 4) paths")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -429,6 +466,15 @@ def main():
     k_med_ms = float(k_ms[len(k_ms) // 2])
     per_rank_kernel_ms = gather_floats(k_avg_ms, world)                  # launch skew between GPUs, if any
 
+    # Package power and shader clock while the headline mode runs (untimed repeat of the step loop, rank 0's card only):
+    # the launch sits at the power cap and the clock is what gives (profiles/r3_power_clock.txt), which is what bounds
+    # the roofline fraction of this arithmetic.  rocm-smi reads sysfs from a side thread; null when it is not there.
+    power = None
+    if rank == 0 and not stub and not a.no_power:
+        wl.set_overlap(a.overlap)
+        power = power_sample(wl, dev_index=wl.dev.index or 0, seconds=2.5)
+        wl.set_overlap(1)
+
     extras = wl.extras(a.steps) if (a.extras and rank == 0 and not stub) else {}
 
     if rank == 0:
@@ -486,7 +532,8 @@ def main():
                                 "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32,
                                 # the second ceiling: share of an ordered launch a SIMD's vector pipe is
                                 # executing, from the same committed counter passes as `traffic` (quoted, not live)
-                                "secondary": {"bound": "valu_fp32", "busy_frac": valu_busy, "source": traffic_src}}
+                                "secondary": {"bound": "valu_fp32", "busy_frac": valu_busy, "source": traffic_src},
+                                "power": power}
             line["ordered"] = {"value": round(fps_ord, 1), "ms_per_step": round(elapsed_ord / a.steps * 1e3, 4),
                                "kernel_ms_avg": round(k_avg_ms, 4), "achieved": round(achieved_ord, 1),
                                "frac": round(achieved_ord / HBM_PEAK_GBS, 4),

@@ -51,6 +51,12 @@ def main():
     print(f"B={B} mode=0x{mode:02X}: launch span {span / 1e3:.1f} us, {ncu} distinct CUs, workgroup lifetime mean "
           f"{life.mean() / 1e3:.2f} us median {np.median(life) / 1e3:.2f} us p90 {np.percentile(life, 90) / 1e3:.2f} us")
     print(f"  mean resident workgroups per CU over the span: {life.sum() / span / ncu:.2f}")
+    # shader clock the launch ran at: s_memtime ticks (stamps 0 and 12, one per shader cycle) over the 100 MHz counter
+    cyc = (s[:, 12] - s[:, 0]).astype(np.float64)
+    ok = (life > 0) & (cyc > 0)
+    ghz = cyc[ok] / life[ok]
+    print(f"  shader clock over a workgroup's life (s_memtime / s_memrealtime): median {np.median(ghz):.3f} GHz, "
+          f"p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}")
     # residency histogram over time
     nb = 20
     edges = np.linspace(0, span, nb + 1)
