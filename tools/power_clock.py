@@ -68,6 +68,20 @@ def main():
         print(f"\n== {name}: {n} launches of {B} frames in {dt:.2f} s = {dt / n * 1e6:.1f} us per launch (stream-ordered)")
         for s in shots[1:6]:
             print("  ", s)
+    # the Q15 chain (config 4): integer cascade (one wave per SIMD, latency-bound) + fixed-point FFT
+    xq = [torch.randint(-2048, 2048, (B, N), device="cuda", dtype=torch.int32).to(torch.int16) for _ in range(4)]
+    oq = [torch.empty((B, N, 2), dtype=torch.int16, device="cuda") for _ in range(4)]
+    ch.reserve(B)
+    ch.set_filter_mode(0x00)
+
+    def qstep():
+        i = k[0] % 4
+        k[0] += 1
+        ch.process_q15(xq[i], out=oq[i])
+    n, dt, shots = sample_while(qstep, SECS)
+    print(f"\n== Q15 chain, default IIR: {n} launches of {B} frames in {dt:.2f} s = {dt / n * 1e6:.1f} us per launch")
+    for s in shots[1:6]:
+        print("  ", s)
     # a copy kernel for comparison: HBM traffic only
     def copy():
         i = k[0] % 4
