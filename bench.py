@@ -316,6 +316,23 @@ class GpuWorkload:
                 ch.set_overlap(1)
             del xqs, oqs
         ch.set_filter_mode(0xA1)
+        # the float chain fed with the ADC's int16 samples (sa_process_f32_i16: 32 KiB in + 64 KiB out per frame; the
+        # same results as the float32 frames give, half the input bytes) -- not the workload BASELINE.json names
+        xis = [torch.randint(-2048, 2048, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+               for _ in range(R)]
+        k = [0]
+
+        def istep():
+            ch.process_f32(xis[k[0] % R], out=self.outs[k[0] % R])
+            k[0] += 1
+        dt = time_it(istep, steps)
+        out["float_chain_from_int16"] = {"frames_per_s": B / dt, "GBps": B * (32768 + 65536) / dt / 1e9}
+        if R > 2:
+            ch.set_overlap(2)
+            dt = time_it(istep, steps)
+            out["float_chain_from_int16_overlap2"] = {"frames_per_s": B / dt, "GBps": B * (32768 + 65536) / dt / 1e9}
+            ch.set_overlap(1)
+        del xis
         return out
 
     def close(self):

@@ -37,7 +37,7 @@ class SpecanError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC]
+    cmd = ["make", "-j4", "-C", CSRC]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
     L.sa_process_q15.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.sa_filter_q15.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.sa_process_f32.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sa_process_f32_i16.argtypes = [H, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.sa_pack_frame.argtypes = [C.POINTER(C.c_int16), C.POINTER(C.c_uint8)]
     L.sa_debug_iir_plan_f32.argtypes = [H, C.POINTER(C.c_float), C.c_int]
     L.sa_iir_plan_from_sos.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.c_int]
@@ -102,7 +103,7 @@ def lib() -> C.CDLL:
                  "sa_feed_command_bytes_ex", "sa_get_transport",
                  "sa_load_sos_f32", "sa_load_sos_f64", "sa_load_sos_q14", "sa_set_window_q15",
                  "sa_set_window_f32", "sa_set_window_mode_q15", "sa_get_window_q15", "sa_process_q15",
-                 "sa_filter_q15", "sa_process_f32", "sa_pack_frame", "sa_debug_iir_plan_f32",
+                 "sa_filter_q15", "sa_process_f32", "sa_process_f32_i16", "sa_pack_frame", "sa_debug_iir_plan_f32",
                  "sa_iir_plan_from_sos"):
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -235,12 +235,18 @@ class SpectrumChain:
         return out
 
     # ------------------------------------------------------------------ data plane
-    def process_f32(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_kind: str = "mag_full"):
+    def process_f32(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, out_kind: str = "mag_full",
+                    scale: float = 1.0 / 2048.0):
         """[B,16384] float32 -> per ``out_kind``: 'mag_full' [B,16384] f32, 'mag_half' [B,8193] f32,
-        'spec_half' [B,8193] complex64, 'time' [B,16384] f32."""
+        'spec_half' [B,8193] complex64, 'time' [B,16384] f32.
+
+        An int16 tensor (the ADC's samples, what the ingest front-end delivers) takes the same float path through
+        sa_process_f32_i16: x = float(sample) * ``scale``, rounded once, no conversion pass; ``scale`` is ignored for
+        float32 input."""
         if out_kind not in _OUT_KINDS:
             raise SpecanError(abi.SA_EINVAL, f"out_kind must be one of {sorted(_OUT_KINDS)}")
-        B = self._check_in(x, torch.float32)
+        from_i16 = x.dtype == torch.int16
+        B = self._check_in(x, torch.int16 if from_i16 else torch.float32)
         if out_kind in ("mag_full", "time"):
             shape, dt = (B, SA_N), torch.float32
         elif out_kind == "mag_half":
@@ -251,8 +257,12 @@ class SpectrumChain:
             out = torch.empty(shape, dtype=dt, device=self.device)
         elif tuple(out.shape) != shape or out.dtype != dt or out.device != self.device or not out.is_contiguous():
             raise SpecanError(abi.SA_ESHAPE, f"out must be a contiguous {dt} tensor of shape {shape}")
-        self._check(self._lib.sa_process_f32(self._h, x.data_ptr(), out.data_ptr(), B, _OUT_KINDS[out_kind],
-                                             self._stream()))
+        if from_i16:
+            self._check(self._lib.sa_process_f32_i16(self._h, x.data_ptr(), float(scale), out.data_ptr(), B,
+                                                     _OUT_KINDS[out_kind], self._stream()))
+        else:
+            self._check(self._lib.sa_process_f32(self._h, x.data_ptr(), out.data_ptr(), B, _OUT_KINDS[out_kind],
+                                                 self._stream()))
         return out
 
     def process_q15(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

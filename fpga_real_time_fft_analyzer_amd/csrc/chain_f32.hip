@@ -21,7 +21,24 @@
 // The factor 1/2 of the split step is folded into the window table (exact in binary fp).
 #include "chain_f32_dev.hpp"
 
+// This file is compiled twice: as it is (float32 frames in: sa_process_f32) and, through chain_f32_i16.hip, with
+// SA_F32_INPUT_I16 = 1 (int16 samples in -- what the board's ADC path delivers, imp/dsp_system_top.vhd:435 -- converted
+// and scaled in the stage-in: sa_process_f32_i16).  Everything behind the stage-in is the same code.
+#ifndef SA_F32_INPUT_I16
+#define SA_F32_INPUT_I16 0
+#endif
+
 namespace {
+
+#if SA_F32_INPUT_I16
+typedef int16_t sa_in_t;
+#define SA_IN_SCALE_PARAM const float in_scale,        // only the int16 instantiations carry the scale
+#define SA_IN_SCALE_ARG in_scale,
+#else
+typedef float sa_in_t;
+#define SA_IN_SCALE_PARAM
+#define SA_IN_SCALE_ARG
+#endif
 
 constexpr int kThreads = 256;
 constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange image (4352 complex)
@@ -106,6 +123,72 @@ __device__ __forceinline__ void dma_chunk_half(const float *__restrict__ xin, in
                                          (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
     }
     __builtin_amdgcn_s_setprio(0);
+}
+
+// int16 samples in (SA_F32_INPUT_I16): a thread's 64 samples are 128 bytes, so ONE round of the same LDS-DMA brings the
+// whole frame (32 KiB): row r = thread r's samples, same wave-private slabs, same XOR swizzle of the 16-byte columns.
+// Column g of a row holds samples 8g .. 8g+7: g < 4 is chunk A, g >= 4 chunk B.  x = float(sample) * scale is rounded once
+// and then takes the window exactly as a float32 input sample does, so the results are those of sa_process_f32 on the
+// converted frame, bit for bit.
+template <bool WINGEN>
+__device__ __forceinline__ void stage_in_chunks(const int16_t *__restrict__ xin, const float in_scale,
+                                                const float4 *__restrict__ wint, const SaIirLaneTab *__restrict__ lt,
+                                                unsigned char *smem, int t, v2f (&d)[32])
+{
+    const uint4 *lds4 = reinterpret_cast<const uint4 *>(smem);
+    const int lane = t & 63, wave = t >> 6, rl = lane >> 3;
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float g0 = 0.f;
+    if constexpr (WINGEN) {
+        pq = *reinterpret_cast<const float4 *>(&lt->wgen[t][0]);
+        g0 = lt->wg0;
+    }
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = wave * 8 + i;                            // slab: rows 8n .. 8n+7
+        const int r = 8 * n + rl;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const int16_t *src = xin + r * 64 + lc * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int sw = (t >> 1) & 7;
+    const v2f Pw = {pq.x, pq.z}, Qw = {pq.y, pq.w}, G0 = {g0, g0}, sc = {in_scale, in_scale};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                              // samples 8g .. 8g+7 of chunk A and of chunk B
+        const uint4 qa = lds4[t * 8 + (g ^ sw)], qb = lds4[t * 8 + ((g + 4) ^ sw)];
+        const unsigned ua[4] = {qa.x, qa.y, qa.z, qa.w}, ub[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                          // four samples of either chunk at a time
+            float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
+            if constexpr (!WINGEN) {                           // table window: win_t[g'][t] = window at 64 t + 4 g' .. + 3
+                wa = wint[(2 * g + u) * 256 + t];
+                wb = wint[(8 + 2 * g + u) * 256 + t];
+            }
+            const float fa[4] = {wa.x, wa.y, wa.z, wa.w}, fb[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * u + e4, j = 8 * g + e;
+                const int ia = (e & 1) ? (int)ua[e >> 1] >> 16 : (int)(short)(ua[e >> 1] & 0xFFFFu);
+                const int ib = (e & 1) ? (int)ub[e >> 1] >> 16 : (int)(short)(ub[e >> 1] & 0xFFFFu);
+                const v2f x = v2f{(float)ia, (float)ib} * sc;   // rounded once: the float32 sample
+                v2f w;
+                if constexpr (WINGEN) {
+                    const v2f cs = {lt->wcs[j][0], lt->wcs[j][1]};
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                        "v_pk_fma_f32 %0, %4, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                        : "=&v"(w) : "v"(Pw), "s"(cs), "v"(G0), "v"(Qw));
+                } else {
+                    w = v2f{fa[e4], fb[e4]};
+                }
+                d[j] = x * w;
+            }
+        }
+    }
 }
 
 template <bool WINGEN>
@@ -448,8 +531,8 @@ __device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w 
 // ---------------------------------------------------------------------------------------------
 // One frame: window -> IIR -> FFT -> split -> store.
 template <int NSEC, bool UNIT, int OUT, bool WINGEN, typename PlanT>
-__device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *__restrict__ out, const int f,
-                                            unsigned char *smem,
+__device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM void *__restrict__ out,
+                                            const int f, unsigned char *smem,
                                             const float4 *__restrict__ winb, const float4 *__restrict__ twT,
                                             const float4 *__restrict__ twB, const float2 *__restrict__ twC,
                                             const SaIirLaneTab *__restrict__ lanetab, const PlanT &ka)
@@ -463,10 +546,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
     const int wave = t >> 6;
     const int lo = lane & 15;          // b in pass B, c in pass C
     const int kq = lane >> 4;
-    const float *xin = in + (size_t)f * SA_NPTS;
-#ifdef SA_STAMPS
-    const int sa_frame = f;
-#endif
+    const sa_in_t *xin = in + (size_t)f * SA_NPTS;
     constexpr bool IIR = NSEC > 0;
     cf a[32];
 #ifdef SA_STAMPS
@@ -476,7 +556,11 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 
     if constexpr (IIR) {
         v2f d[32];
+#if SA_F32_INPUT_I16
+        stage_in_chunks<WINGEN>(xin, in_scale, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
+#else
         stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
+#endif
         SA_STAMP(1);
 #if SA_AB_PROBE != 3                    // probe 3: the whole cascade skipped (window -> FFT)
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
@@ -512,6 +596,31 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
         // thread picks z[256 m1 + t] straight out of the image; the window comes as 16-byte loads of
         // the pass-A layout (winb[p][t] = window at samples 512(2p)+2t, +1, 512(2p+1)+2t, +1).
         // 8 + 8 vector-memory instructions per wave and round instead of 32 8-byte loads.
+#if SA_F32_INPUT_I16
+        {
+            // int16 samples: the whole frame (32 KiB) in one round; z[256 m1 + t] = (x[2 i], x[2 i + 1]) is one dword
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = wave * 8 + i;
+                const int16_t *src = xin + n * 512 + lane * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            const unsigned *ldu = reinterpret_cast<const unsigned *>(smem);
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                const float4 w = winb[pp * 256 + t];
+                const unsigned u0 = ldu[256 * (2 * pp) + t], u1 = ldu[256 * (2 * pp + 1) + t];
+                const cf z0 = cf{(float)(int)(short)(u0 & 0xFFFFu), (float)((int)u0 >> 16)} * cf{in_scale, in_scale};
+                const cf z1 = cf{(float)(int)(short)(u1 & 0xFFFFu), (float)((int)u1 >> 16)} * cf{in_scale, in_scale};
+                a[safft::brev(2 * pp, 5)] = {z0.x * w.x, z0.y * w.y};
+                a[safft::brev(2 * pp + 1, 5)] = {z1.x * w.z, z1.y * w.w};
+            }
+        }
+#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1) __syncthreads();
@@ -534,6 +643,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
                 a[safft::brev(16 * h + 2 * pp + 1, 5)] = {z1.x * w.z, z1.y * w.w};
             }
         }
+#endif
     }
 
     // ---- pass A: 32-point FFT over m1 (stride 256), then twiddle W_8192^(k1*m2), m2 = t
@@ -759,7 +869,7 @@ __device__ __forceinline__ void chain_frame(const float *__restrict__ in, void *
 }
 
 template <int NSEC, bool UNIT, int OUT, bool WINGEN>
-__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
                                                                  const float4 *__restrict__ twT,
@@ -771,12 +881,12 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const float *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int f = blockIdx.x;
     if (f >= batch) return;
-    chain_frame<NSEC, UNIT, OUT, WINGEN>(in, out, f, smem, winb, twT, twB, twC, lanetab, ka);
+    chain_frame<NSEC, UNIT, OUT, WINGEN>(in, SA_IN_SCALE_ARG out, f, smem, winb, twT, twB, twC, lanetab, ka);
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
 template <int NSEC, bool UNIT>
-__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM
                                                                 float *__restrict__ out, int batch,
                                                                 const float4 *__restrict__ wint_plain,
                                                                 const SaIirLaneTab *__restrict__ lanetab,
@@ -789,7 +899,11 @@ __global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const float *__re
     if (f >= batch) return;
     v2f d[32];
     const float4 *wint = NSEC > 0 ? reinterpret_cast<const float4 *>(lanetab->win_t) : wint_plain;
+#if SA_F32_INPUT_I16
+    stage_in_chunks<false>(in + (size_t)f * SA_NPTS, in_scale, wint, lanetab, smem, t, d);
+#else
     stage_in_chunks<false>(in + (size_t)f * SA_NPTS, wint, lanetab, smem, t, d);
+#endif
     if constexpr (NSEC > 0) iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
     // Stage-out, the stage-in run backwards: each thread owns 64 consecutive samples, so storing straight
     // from the registers puts every lane of a store instruction into another 256-byte block (measured 5x
@@ -829,7 +943,7 @@ hipError_t set_lds(K kernel)
 
 }  // namespace
 
-#ifdef SA_STAMPS
+#if defined(SA_STAMPS) && !SA_F32_INPUT_I16
 extern "C" int sa_debug_set_stamps(void *p)
 {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sa_stamps), &p, sizeof(p));
@@ -839,8 +953,8 @@ extern "C" int sa_debug_set_stamps(void *p)
 namespace {
 
 template <int NSEC, bool UNIT>
-hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK &ka,
-                       hipStream_t stream, hipEvent_t stop)
+hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int batch, int out_kind, const SaF32Tables &tb,
+                       const SaIirK &ka, hipStream_t stream, hipEvent_t stop)
 {
     const dim3 grid(batch), block(kThreads);
     hipError_t e = hipSuccess;
@@ -850,7 +964,7 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
                               : chain_f32_kernel<NSEC, UNIT, OUTK, false>;                             \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, out, batch, tb.win_b, tb.twT, \
+        hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, SA_IN_SCALE_ARG out, batch, tb.win_b, tb.twT, \
                            tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
     switch (out_kind) {
@@ -861,7 +975,7 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
             auto kern = time_f32_kernel<NSEC, UNIT>;
             e = set_lds(kern);
             if (e != hipSuccess) return e;
-            hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, reinterpret_cast<float *>(out), batch,
+            hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, SA_IN_SCALE_ARG reinterpret_cast<float *>(out), batch,
                                tb.win_t, tb.lanetab, ka);
             break;
         }
@@ -874,22 +988,30 @@ hipError_t launch_nsec(const float *in, void *out, int batch, int out_kind, cons
 }  // namespace
 
 // tb.iir->nsec is the PADDED section count (0, 2, 4 or 6; see build_plan in specan_abi.cpp).
+#if SA_F32_INPUT_I16
+hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &tb,
+                                   hipStream_t stream, hipEvent_t stop)
+#else
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
                                hipStream_t stream, hipEvent_t stop)
+#endif
 {
+#if !SA_F32_INPUT_I16
+    const float in_scale = 1.f;         // the float32 kernels do not take it
+#endif
     if (batch <= 0) return hipSuccess;
     static const SaIirK kNoIir = {};
     const int nsec = tb.iir ? tb.iir->nsec : 0;
     const SaIirK &ka = nsec > 0 ? *tb.iir : kNoIir;
     const bool unit = nsec > 0 && ka.unit != 0;
     switch (nsec) {
-        case 0: return launch_nsec<0, false>(in, out, batch, out_kind, tb, ka, stream, stop);
-        case 2: return unit ? launch_nsec<2, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<2, false>(in, out, batch, out_kind, tb, ka, stream, stop);
-        case 4: return unit ? launch_nsec<4, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<4, false>(in, out, batch, out_kind, tb, ka, stream, stop);
-        case 6: return unit ? launch_nsec<6, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<6, false>(in, out, batch, out_kind, tb, ka, stream, stop);
+        case 0: return launch_nsec<0, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
+        case 2: return unit ? launch_nsec<2, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
+                            : launch_nsec<2, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
+        case 4: return unit ? launch_nsec<4, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
+                            : launch_nsec<4, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
+        case 6: return unit ? launch_nsec<6, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
+                            : launch_nsec<6, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
         default: return hipErrorInvalidValue;
     }
 }

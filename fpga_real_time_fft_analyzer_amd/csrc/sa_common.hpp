@@ -159,6 +159,9 @@ struct SaF32Tables {
 // the dispatch packet itself: no marker packet between two launches, unlike hipEventRecord after the launch).
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
                                hipStream_t stream, hipEvent_t stop);
+// the same chain on int16 samples (chain_f32_i16.hip): x = float(sample) * in_scale, then exactly the float32 path
+hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &t,
+                                   hipStream_t stream, hipEvent_t stop);
 // the 512-thread form (chain_f32_w8.hip): IIR modes with the three spectrum outputs; returns hipErrorNotSupported
 // for anything else (the caller then takes sa_launch_chain_f32)
 hipError_t sa_launch_chain_f32_w8(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,

@@ -1360,6 +1360,32 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     return end_call(h, c);
 }
 
+int sa_process_f32_i16(sa_handle *h, const int16_t *in, float scale, void *out, int batch, int out_kind, void *stream)
+{
+    if (!h) return SA_EINVAL;
+    if (batch < 0) return fail(h, SA_ESHAPE, "sa_process_f32_i16: negative batch");
+    if (out_kind < SA_OUT_MAG_FULL || out_kind > SA_OUT_TIME) return fail(h, SA_EINVAL, "sa_process_f32_i16: bad out_kind");
+    if (!(scale == scale) || scale - scale != 0.f) return fail(h, SA_EINVAL, "sa_process_f32_i16: scale is not finite");
+    if (batch == 0) return SA_OK;
+    if (!in || !out) return fail(h, SA_EINVAL, "sa_process_f32_i16: NULL tensor");
+    if (h->filter_mode == SA_FILTER_WIDE)
+        return fail(h, SA_ESTATE, "sa_process_f32_i16: filter mode 0xA2 (Q2.14) belongs to the Q15 path; use 0xA1 with sa_load_sos_f32");
+    SA_HIP(h, hipSetDevice(h->device));
+    CallCtx c;
+    { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr,
+                     h->d_twT8, h->d_lt8_custom, nullptr};
+    if (h->filter_mode == SA_FILTER_DEFAULT) {
+        t.lanetab = h->d_lt_default;
+        t.iir = &h->plan_default;
+    } else if (h->filter_mode == SA_FILTER_CUSTOM) {
+        t.lanetab = h->d_lt_custom;
+        t.iir = &h->plan_custom;
+    }
+    SA_HIP(h, sa_launch_chain_f32_i16(in, scale, out, batch, out_kind, t, c.stream, c.stop));
+    return end_call(h, c);
+}
+
 int sa_pack_frame(const int16_t *iq_host, uint8_t *frame_bytes)
 {
     if (!iq_host || !frame_bytes) return SA_EINVAL;

@@ -205,6 +205,13 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
  * section 2).  Callers that need 1e-5 on such designs need float64, which this path does not offer. */
 int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_kind, void *stream);
 
+/* The float path fed with the ADC's samples (build extension): in [B,16384] int16 device -- the board delivers
+ * 12-bit samples sign-extended to int16 (imp/dsp_system_top.vhd:435) and that is what the ingest front-end moves over
+ * PCIe.  x = (float)sample * scale is rounded once in the stage-in (scale = 1/2048 maps the ADC range to [-1, 1)) and
+ * then takes exactly the float32 path: the results are those of sa_process_f32() on the converted frames, bit for bit,
+ * without the conversion pass and with half the input bytes (32 KiB per frame, one fetch round instead of two). */
+int sa_process_f32_i16(sa_handle *h, const int16_t *in, float scale, void *out, int batch, int out_kind, void *stream);
+
 /* Host helper: view of one frame as the byte stream sequ2 emits.  On little-endian hosts the
  * Q15 output already is that stream; this copies 65536 bytes and is provided for symmetry with
  * gui.py:250-260 (decode side). */

@@ -325,6 +325,52 @@ def test_overlap_streams_are_picked_to_run_side_by_side(chain_cls, torch_mod):
         c.close()
 
 
+@pytest.mark.parametrize("scale", [1.0 / 2048.0, 3.1e-4])
+def test_int16_samples_take_the_float_path_bit_for_bit(ch, torch_mod, oracle, scale):
+    """sa_process_f32_i16: the ADC's int16 samples (imp/dsp_system_top.vhd:435) converted and scaled in the stage-in.
+    x = float(sample) * scale is rounded once, so every output must EQUAL what sa_process_f32 gives on the frames
+    converted by the caller -- every filter mode and padded section count, cosine and table window, every output
+    kind -- and, through it, the float64 oracle within the float tolerance."""
+    from scipy import signal
+    torch = torch_mod
+    rng = np.random.default_rng(17)
+    xi = rng.integers(-2048, 2048, size=(5, N)).astype(np.int16)
+    xi[1] = rng.integers(-32768, 32768, size=N).astype(np.int16)          # full-scale samples
+    xi[2, :4] = [-32768, 32767, -1, 0]
+    d_i = _dev(torch, xi)
+    d_f = (d_i.to(torch.float32) * np.float32(scale)).contiguous()            # one rounding, as the kernel does it
+    cascades = [None, signal.butter(12, 0.2, output="sos"), signal.cheby1(7, 1.0, 0.3, output="sos"),
+                signal.ellip(4, 0.5, 40.0, [0.1, 0.3], btype="bandpass", output="sos")[:3], signal.butter(3, 0.4, output="sos")]
+    for win in (None, np.blackman(N).astype(np.float32)):
+        if win is not None:
+            ch.set_window_f32(win)
+        for sos in cascades:
+            if sos is None:
+                ch.set_filter_mode(0xB1)
+            else:
+                ch.load_sos(sos)
+                ch.set_filter_mode(0xA1)
+            for kind in ("mag_full", "mag_half", "spec_half", "time"):
+                a = ch.process_f32(d_i, out_kind=kind, scale=scale)
+                b = ch.process_f32(d_f, out_kind=kind)
+                assert torch.equal(torch.view_as_real(a) if a.is_complex() else a,
+                                   torch.view_as_real(b) if b.is_complex() else b), (win is not None, kind, None if sos is None else len(sos))
+        ch.set_filter_mode(0x00)                                             # the RTL's default taps as reals
+        assert torch.equal(ch.process_f32(d_i, scale=scale), ch.process_f32(d_f))
+    ch.set_window_f32(None)
+    # and against the float64 oracle (Hann, the headline cascade)
+    ch2_sos = cascades[1]
+    ch.set_window_f32(None)
+    ch.load_sos(ch2_sos)
+    ch.set_filter_mode(0xA1)
+    xf = (xi.astype(np.float32) * np.float32(scale)).astype(np.float32)
+    _, _, mag = oracle.chain_fp(xf, ch2_sos)
+    got = ch.process_f32(d_i, scale=scale).cpu().numpy()
+    assert rel_maxnorm(got, mag) <= 1e-5
+    with pytest.raises(Exception):
+        ch.process_f32(d_i, scale=float("nan"))
+
+
 def test_edge_inputs(ch, torch_mod):
     g = load_golden("g2_config1.npz")
     ch.load_sos(g["sos"])

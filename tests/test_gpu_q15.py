@@ -462,3 +462,14 @@ def test_ingest_double_buffer_feeds_the_chain(ch, torch_mod, oracle):
     outs = [ch.process_q15(xd).cpu().numpy() for xd in feeder.feed(batches)]
     ref = oracle.chain_q15(stream[:5 * N].reshape(5, N))
     assert np.array_equal(np.concatenate(outs), ref)
+    # the same int16 batches into the FLOAT chain (sa_process_f32_i16: no conversion pass on the device)
+    from scipy import signal
+    sos = signal.butter(6, 0.25, output="sos")
+    ch.load_sos(sos)
+    ch.set_filter_mode(0xA1)
+    fouts = [ch.process_f32(xd).cpu().numpy() for xd in DeviceFeeder(0, max_batch=8).feed(batches)]
+    xf = (stream[:5 * N].reshape(5, N).astype(np.float32) / np.float32(2048.0)).astype(np.float32)
+    _, _, mag = oracle.chain_fp(xf, sos)
+    got = np.concatenate(fouts)
+    assert (np.abs(got - mag).max(axis=1) / np.abs(mag).max(axis=1)).max() <= 1e-5
+    ch.set_filter_mode(0xB1)
