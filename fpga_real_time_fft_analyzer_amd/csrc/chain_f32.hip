@@ -605,7 +605,7 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
                 const int n = wave * 8 + i;
                 const int16_t *src = xin + n * 512 + lane * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
             }
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();
@@ -630,7 +630,7 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
                 const int n = wave * 8 + i;
                 const float *src = xin + h * 8192 + n * 256 + lane * 4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
             }
             __builtin_amdgcn_s_setprio(0);
             __syncthreads();

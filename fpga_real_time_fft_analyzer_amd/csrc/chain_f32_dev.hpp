@@ -15,7 +15,8 @@ namespace {
 #define SA_AB_PROBE 0         // timing probes of A/B builds (results invalid); 0 = the product
 #endif
 #ifndef SA_DMA_AUX
-#define SA_DMA_AUX 0          // cache policy bits of the input LDS-DMA (2 = nontemporal); A/B builds only
+#define SA_DMA_AUX 2          // cache policy bits of the input LDS-DMA: 2 = nontemporal (a frame is read once); 0 in A/B
+                              // builds: 132.2 -> 130.3 us stream-ordered, no difference with two launches in flight
 #endif
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
