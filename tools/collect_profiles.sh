@@ -19,7 +19,8 @@ with open(dst, "w") as fh:
     w = csv.writer(fh)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
-        w.writerow([r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+        nm = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        w.writerow([nm.split("(")[0] + (" [int16 samples in]" if "(short const*" in nm else ""), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 PY
 }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 bench.py --overlap 1 --no-cpu-baseline --extras --steps 20 > $OUT/${TAG}_bench_ordered_under_rocprof.json 2> $OUT/bench_ordered_under_rocprof.err
