@@ -492,7 +492,7 @@ def main():
         power = power_sample(wl, dev_index=wl.dev.index or 0, seconds=2.5)
         wl.set_overlap(1)
         if power:                        # energy of one step at that power: what a power-limited launch is made of
-            power["mj_per_step"] = round(power["socket_w"] * elapsed / a.steps, 1)
+            power["mj_per_step"] = round(power["socket_w"] * elapsed / a.steps * 1e3, 1)
 
     extras = wl.extras(a.steps) if (a.extras and rank == 0 and not stub) else {}
 
