@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run on the GPU box (test infrastructure: uses the oracle): random batch sizes, filter modes, coefficient
 uploads, window modes and input scales through the Q15 path, bit-exact against the integer model every time;
-float chain on random batch sizes within tolerance.  Round 3: the launch mode changes at random (ordered, two or three
+float chain on random batch sizes (float32 frames or int16 samples in) within tolerance.  Round 3: the launch mode changes at random (ordered, two or three
 launches in flight: sa_set_overlap), in overlap mode up to three calls are issued back to back before the flush, with control-plane
 calls between them.  usage: soak.py SECONDS [SEED]"""
 import os
@@ -22,7 +22,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ch = SpectrumChain(0)
 sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]
 t0 = time.time()
-n_q15 = n_f32 = 0
+n_q15 = n_f32 = n_i16 = 0
 worst = 0.0
 last = t0
 n_mode = [0, 0, 0, 0]
@@ -65,7 +65,14 @@ while time.time() - t0 < budget:
         ch.load_sos(sos)
         ch.set_filter_mode(0xA1 if rng.integers(0, 2) else 0xB1)
         _, _, mag = orc.chain_fp(xf, sos if ch.filter_mode == 0xA1 else None)
-        xfd = torch.from_numpy(xf).cuda()
+        if rng.integers(0, 2):                              # the same chain from int16 samples (sa_process_f32_i16)
+            xi = np.clip(np.round(xf * 2048.0), -32768, 32767).astype(np.int16)
+            xf = (xi.astype(np.float32) * np.float32(1.0 / 2048.0)).astype(np.float32)
+            _, _, mag = orc.chain_fp(xf, sos if ch.filter_mode == 0xA1 else None)
+            xfd = torch.from_numpy(xi).cuda()
+            n_i16 += 1
+        else:
+            xfd = torch.from_numpy(xf).cuda()
         outf = ch.process_f32(xfd)
         if depth > 1:
             ch.flush()
@@ -79,5 +86,5 @@ while time.time() - t0 < budget:
     if time.time() - last > 30:
         last = time.time()
         print(f"  {n_q15} Q15 cases bit-exact, {n_f32} float cases (worst {worst:.2e}) after {last - t0:.0f} s", flush=True)
-print(f"soak ok: {n_q15} Q15 cases bit-exact, {n_f32} float cases within 1e-5 (worst {worst:.2e}) in {time.time() - t0:.0f} s; "
+print(f"soak ok: {n_q15} Q15 cases bit-exact, {n_f32} float cases ({n_i16} of them from int16 samples) within 1e-5 (worst {worst:.2e}) in {time.time() - t0:.0f} s; "
       f"bursts in ordered / depth-2 / depth-3 mode: {n_mode[1]} / {n_mode[2]} / {n_mode[3]}")
