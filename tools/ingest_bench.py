@@ -6,7 +6,9 @@ Reports frames/s end to end and the host->device rate against the PCIe bound DES
 socket / file reader delivers) and (b) the same with the host copy taken out (samples produced in pinned
 memory).  With --events it also prints, per batch, the copy and kernel intervals measured with HIP events on
 their own streams, which shows the copy of batch k+1 running under the kernels of batch k.
-usage: ingest_bench.py [batch_frames] [n_batches] [mode]"""
+--float: the same int16 batches into the FLOAT chain (sa_process_f32_i16, mode 0xA1 with the headline cascade): no
+conversion pass on the device, the PCIe volume of the Q15 path.
+usage: ingest_bench.py [batch_frames] [n_batches] [mode] [--events] [--float]"""
 import os
 import sys
 import time
@@ -25,22 +27,33 @@ torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
 N = 16384
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-mode = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0xB1
+mode = int(sys.argv[3], 0) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 0xB1
+FLOAT = "--float" in sys.argv
 
 ch = SpectrumChain(0)
+if FLOAT:
+    ch.load_sos(np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"])
 ch.set_filter_mode(mode)
 ch.reserve(B)
 rng = np.random.default_rng(0)
 host = [rng.integers(-2048, 2048, size=(B, N), dtype=np.int16) for _ in range(4)]       # 4 distinct batches, reused
-out = [torch.empty((B, N, 2), dtype=torch.int16, device="cuda") for _ in range(2)]
+out = [torch.empty((B, N) if FLOAT else (B, N, 2), dtype=torch.float32 if FLOAT else torch.int16, device="cuda")
+       for _ in range(2)]
 feeder = DeviceFeeder(0, max_batch=B)
+
+
+def process(xd, o):
+    if FLOAT:
+        ch.process_f32(xd, out=o)          # int16 tensor in: sa_process_f32_i16
+    else:
+        ch.process_q15(xd, out=o)
 
 
 def run(batches):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i, xd in enumerate(feeder.feed(batches)):
-        ch.process_q15(xd, out=out[i & 1])
+        process(xd, out[i & 1])
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -61,11 +74,11 @@ def pure_h2d():
 def pure_kernels():
     xd = torch.from_numpy(host[0]).cuda()
     for _ in range(3):
-        ch.process_q15(xd, out=out[0])
+        process(xd, out[0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(20):
-        ch.process_q15(xd, out=out[0])
+        process(xd, out[0])
     torch.cuda.synchronize()
     return 20 * B / (time.perf_counter() - t0)
 
@@ -76,7 +89,7 @@ h2d = pure_h2d()
 kfps = pure_kernels()
 print(f"batch {B} frames x {NB} batches, filter mode 0x{mode:02X}")
 print(f"  pinned host -> device copy alone      : {h2d / 1e9:6.1f} GB/s = {h2d / (N * 2) / 1e6:5.2f} M frames/s   (PCIe Gen5 x16 spec 63 GB/s = 1.92 M frames/s)")
-print(f"  Q15 kernels alone, inputs resident    : {kfps / 1e6:5.2f} M frames/s")
+print(f"  {'float chain from int16' if FLOAT else 'Q15 kernels'} alone, inputs resident: {kfps / 1e6:5.2f} M frames/s")
 print(f"  feeder end to end (numpy -> pinned -> device -> path): {NB * B / dt / 1e6:5.2f} M frames/s = {NB * B * N * 2 / dt / 1e9:5.1f} GB/s of samples")
 # the host copy into the staging buffer is part of the feeder; how much of the time is it?
 t0 = time.perf_counter()
@@ -102,7 +115,7 @@ if "--events" in sys.argv:
             c1.record(cs)
         torch.cuda.current_stream().wait_event(c1)
         k0.record()
-        ch.process_q15(feeder._dev[slot][:B], out=out[slot])
+        process(feeder._dev[slot][:B], out[slot])
         k1.record()
         ev.append((c0, c1, k0, k1))
     torch.cuda.synchronize()
