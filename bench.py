@@ -306,13 +306,15 @@ class GpuWorkload:
                 ch.set_filter_mode(cmd)
                 dt = time_it(qstep, 5)
                 out[name + tag] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
-            if R > 2:        # config 4 with two launches in flight: the FFT of batch k under the filter of batch k+1
-                ch.set_overlap(2)
+            for depth in (2, 3):   # config 4 with launches in flight: the FFT of batch k under the filter of batch k+1
+                if R <= depth:
+                    continue
+                ch.set_overlap(depth)
                 ch.reserve(B)
                 ch.set_filter_mode(0x00)
-                dt = time_it(qstep, 6)
-                out["config4_q15_default_iir" + tag + "_overlap2"] = {"frames_per_s": B / dt,
-                                                                     "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+                dt = time_it(qstep, 12)
+                out["config4_q15_default_iir" + tag + f"_overlap{depth}"] = {"frames_per_s": B / dt,
+                                                                            "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
                 ch.set_overlap(1)
             del xqs, oqs
         ch.set_filter_mode(0xA1)
