@@ -16,7 +16,7 @@
 #include <type_traits>
 #include "../../include/specan.h"
 
-#ifdef SA_STAMPS
+#if defined(SA_STAMPS) && !defined(SA_Q15_SECOND_TU)
 // diagnostic build only: per wave {s_memrealtime at start, at end, HW_ID | XCC_ID << 32} (tools/q15_placement.py)
 __device__ unsigned long long *g_q15_stamps = nullptr;
 extern "C" int sa_debug_set_q15_stamps(void *p)
@@ -74,11 +74,23 @@ __device__ __forceinline__ int lo16(unsigned v) { return (int)(short)(v & 0xFFFF
 __device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
 
 // ------------------------------------------------------------------------------------------ IIR
-constexpr int kTile = 256;            // samples per staging tile
+// Tile size: 256 samples in this file's own build.  chain_q15_t128.hip compiles the integer cascade a second time with
+// 128-sample tiles (SA_Q15_SECOND_TU): a cascade workgroup then holds 24 KiB of LDS instead of 48.75 KiB and fits
+// beside an FFT workgroup AND another cascade -- what overlap mode wants (10.0 vs 9.3 M frames/s at depth 2); the
+// smaller tile costs 4 % when launches run one after the other, which is why both exist.
+#ifndef SA_Q15_TILE
+#define SA_Q15_TILE 256
+#endif
+constexpr int kTile = SA_Q15_TILE;    // samples per staging tile
 constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
 constexpr int kFramesPerWave = 4;      // one frame per 16-lane row: lane 0..5 of the row = section 0..5
+// moving a tile between memory and LDS: 16 bytes (8 samples) per lane, kTile / 8 lanes per frame row
+constexpr int kTileLanes = kTile / 8;                       // lanes that cover one row of a tile (32; 16 for 128-sample tiles)
+constexpr int kTileRows = 64 / kTileLanes;                  // rows a wave covers per pass
+constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's four frames
+static_assert(kTile % 32 == 0 && kTileLanes <= 64 && kTileRows * kTilePasses == kFramesPerWave, "tile geometry");
 
 // full-rate 24-bit multiply-add (samples are 16-bit, taps 8-bit); the compiler otherwise falls back to
 // the quarter-rate v_mul_lo_u32 for some of the products
@@ -169,8 +181,8 @@ struct BiqQ14 {
 
 // window + stage one tile of 8 frames x 256 samples into LDS (16 B per lane, two rows per instruction)
 struct Q15TileRegs {
-    uint4 x[kFramesPerWave / 2];
-    uint4 c[kFramesPerWave / 2];
+    uint4 x[kTilePasses];
+    uint4 c[kTilePasses];
 };
 
 // issue the global loads of one tile (4 frames x 256 samples and the matching ROM words), 16 B per lane
@@ -178,9 +190,9 @@ __device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, co
                                               int batch, int n0, int lane, Q15TileRegs &r)
 {
 #pragma unroll
-    for (int i = 0; i < kFramesPerWave / 2; ++i) {
-        const int row = 2 * i + (lane >> 5);
-        const int col = (lane & 31) * 8;
+    for (int i = 0; i < kTilePasses; ++i) {
+        const int row = kTileRows * i + lane / kTileLanes;
+        const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
         r.x[i] = make_uint4(0, 0, 0, 0);
         if (f < batch) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
@@ -192,9 +204,9 @@ __device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, co
 __device__ __forceinline__ void q15_store_tile(const Q15TileRegs &r, int16_t (*tin)[kRowPitch], int lane, int win_mode)
 {
 #pragma unroll
-    for (int i = 0; i < kFramesPerWave / 2; ++i) {
-        const int row = 2 * i + (lane >> 5);
-        const int col = (lane & 31) * 8;
+    for (int i = 0; i < kTilePasses; ++i) {
+        const int row = kTileRows * i + lane / kTileLanes;
+        const int col = (lane % kTileLanes) * 8;
         const unsigned xs[4] = {r.x[i].x, r.x[i].y, r.x[i].z, r.x[i].w};
         const unsigned cs[4] = {r.c[i].x, r.c[i].y, r.c[i].z, r.c[i].w};
 #pragma unroll
@@ -226,9 +238,9 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
                                                int f0, int batch, int n0, int lane, int col_mask = 0x7fffffff)
 {
 #pragma unroll
-    for (int i = 0; i < kFramesPerWave / 2; ++i) {
-        const int row = 2 * i + (lane >> 5);
-        const int col = (lane & 31) * 8;
+    for (int i = 0; i < kTilePasses; ++i) {
+        const int row = kTileRows * i + lane / kTileLanes;
+        const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
         const int sc = (src_col + col) & col_mask;      // 8-sample chunks: a ring wraps between chunks only
         uint4 ov;
@@ -636,9 +648,9 @@ __device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const i
                                               int batch, int n0, int lane)
 {
 #pragma unroll
-    for (int i = 0; i < kFramesPerWave / 2; ++i) {
-        const int row = 2 * i + (lane >> 5);
-        const int col = (lane & 31) * 8;
+    for (int i = 0; i < kTilePasses; ++i) {
+        const int row = kTileRows * i + lane / kTileLanes;
+        const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
         const int sc = (src_col + col) & (kRing - 1);       // 8-sample chunks: the ring wraps between chunks only
         const int4 a = *reinterpret_cast<const int4 *>(&src[row][sc]);
@@ -715,9 +727,9 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
             // window the tile and put it into its half of the input ring
             int16_t (*dst)[kInPitch] = tin;
 #pragma unroll
-            for (int i = 0; i < kFramesPerWave / 2; ++i) {
-                const int row = 2 * i + (lane >> 5);
-                const int col = (k & 1) * kTile + (lane & 31) * 8;
+            for (int i = 0; i < kTilePasses; ++i) {
+                const int row = kTileRows * i + lane / kTileLanes;
+                const int col = (k & 1) * kTile + (lane % kTileLanes) * 8;
                 const unsigned xs[4] = {pre.x[i].x, pre.x[i].y, pre.x[i].z, pre.x[i].w};
                 const unsigned cs[4] = {pre.c[i].x, pre.c[i].y, pre.c[i].z, pre.c[i].w};
                 unsigned o[4];
@@ -988,8 +1000,13 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 
 }  // namespace
 
+#ifdef SA_Q15_SECOND_TU
+hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
+                                     const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
+#else
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
                                 const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
+#endif
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
@@ -1021,6 +1038,7 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
     return hipGetLastError();
 }
 
+#ifndef SA_Q15_SECOND_TU
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
 {
@@ -1033,3 +1051,4 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     hipExtLaunchKernelGGL(k, grid, block, lds, stream, nullptr, stop, 0, in_time, out_iq, batch, p, t.rom, t.tw);
     return hipGetLastError();
 }
+#endif

@@ -174,5 +174,8 @@ struct SaQ15Tables {
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
                                 const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
+// the same cascade with 128-sample tiles (chain_q15_t128.hip): for launches that overlap (half the LDS per workgroup)
+hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
+                                     const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);

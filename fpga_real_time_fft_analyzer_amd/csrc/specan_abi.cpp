@@ -1317,7 +1317,17 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
         return end_call(h, c);
     }
     { const int rc = ensure_work(h, c.slot, batch, c.captured); if (rc != SA_OK) return rc; }
-    SA_HIP(h, sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr));
+    // two launches in flight take the cascade with 128-sample tiles: a second cascade then fits a CU's LDS beside the first
+    // one and an FFT workgroup (measured: 10.0 vs 9.3 M frames/s at depth 2; at depth 3 the 256-sample tiles are ahead,
+    // 9.6 vs 9.3, and stream-ordered by 4 %: tools/q15_overlap_depth.py)
+#ifdef SA_AB_Q15_NO_T128               // A/B builds only: always the 256-sample tiles
+    const bool small_tiles = false;
+#else
+    const bool small_tiles = c.overlapped && h->overlap == 2;
+#endif
+    SA_HIP(h, small_tiles
+                  ? sa_launch_filter_q15_t128(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr)
+                  : sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr));
     SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream, c.stop));
     return end_call(h, c);
 }
