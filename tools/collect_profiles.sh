@@ -20,7 +20,7 @@ with open(dst, "w") as fh:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
         nm = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-        w.writerow([nm.split("(")[0] + (" [int16 samples in]" if "(short const*" in nm else ""), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+        w.writerow([nm.split("(")[0] + (" [int16 samples in]" if "(short const*" in nm and "_f32_kernel" in nm else ""), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 PY
 }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 bench.py --overlap 1 --no-cpu-baseline --extras --steps 20 > $OUT/${TAG}_bench_ordered_under_rocprof.json 2> $OUT/bench_ordered_under_rocprof.err
