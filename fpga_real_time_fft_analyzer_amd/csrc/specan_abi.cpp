@@ -638,12 +638,15 @@ int end_call(sa_handle *h, const CallCtx &c)
 }
 
 // Workspace of a launch slot, grown without touching launches in flight (see sa_handle::retired).
-int ensure_work(sa_handle *h, int slot, int frames, bool captured)
+// `geometric`: grow by at least half (process calls with creeping batch sizes); exact sizing where the size is copied
+// from another slot -- sa_set_overlap gave every slot max(the others, 1.5 x its own), and two slots leap-frogged each
+// other by a factor 1.5 per mode change until hipMalloc failed (found by a 10-minute soak, seed 77).
+int ensure_work(sa_handle *h, int slot, int frames, bool captured, bool geometric = true)
 {
     if (frames <= h->work_frames[slot]) return SA_OK;
     if (captured) return fail(h, SA_ESTATE, "workspace growth inside a stream capture: call sa_reserve() first");
     long want = frames, geo = (long)h->work_frames[slot] + h->work_frames[slot] / 2;
-    if (geo > want) want = geo;
+    if (geometric && geo > want) want = geo;
     void *p = nullptr;
     SA_HIP(h, hipMalloc(&p, (size_t)want * SA_NPTS * sizeof(int16_t)));
     if (h->d_work[slot]) h->retired.push_back(h->d_work[slot]);
@@ -1055,7 +1058,7 @@ int sa_set_overlap(sa_handle *h, int depth)
         // every slot starts with the workspace the handle already has somewhere
         int most = 0;
         for (int j = 0; j < sa_handle::kMaxOverlap; ++j) most = h->work_frames[j] > most ? h->work_frames[j] : most;
-        const int rc = ensure_work(h, i, most, false);
+        const int rc = ensure_work(h, i, most, false, /*geometric=*/false);
         if (rc != SA_OK) return rc;
     }
     h->overlap = depth;

@@ -173,6 +173,30 @@ def test_overlapped_launches_q15(ch, torch_mod, oracle):
     assert np.array_equal(ch.process_q15(_dev(torch, xs[3])).cpu().numpy(), got[3])
 
 
+def test_mode_changes_do_not_grow_the_workspace(chain_cls, torch_mod):
+    """sa_set_overlap gives every launch slot the workspace the largest slot has.  With the geometric growth of the
+    process calls applied there as well, two slots leap-frogged each other by a factor 1.5 per mode change until
+    hipMalloc failed (a 10-minute soak found it).  300 mode changes with batches of changing size must leave the
+    device's free memory where a handful of workspaces put it."""
+    torch = torch_mod
+    c = chain_cls(0)
+    c.set_filter_mode(0x00)
+    rng = np.random.default_rng(4)
+    x = torch.zeros((257, N), dtype=torch.int16, device="cuda")
+    out = torch.empty((257, N, 2), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(300):
+        c.set_overlap(int(rng.choice([1, 2, 3])))
+        B = int(rng.choice([1, 16, 100, 129, 200, 257]))
+        c.process_q15(x[:B], out=out[:B])
+        c.flush()
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    c.close()
+    assert used < 256 * 1024 * 1024, f"{used / 2**20:.0f} MiB of workspace after 300 mode changes"
+
+
 def test_random_wide_cascades(ch, torch_mod, oracle):
     """Wide mode (0xA2): random Q2.14 cascades of 1..6 sections, any int16 tap (saturating accumulators make
     unstable ones well defined), both window modes, bit-exact against the integer model."""
