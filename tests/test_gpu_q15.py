@@ -197,6 +197,29 @@ def test_mode_changes_do_not_grow_the_workspace(chain_cls, torch_mod):
     assert used < 256 * 1024 * 1024, f"{used / 2**20:.0f} MiB of workspace after 300 mode changes"
 
 
+def test_handles_come_and_go_without_leaking(chain_cls, torch_mod):
+    """120 handles created, put into overlap mode, used on both paths and destroyed: device memory returns to where it
+    was (tables, workspaces, streams and events are the handle's own and sa_destroy releases them)."""
+    torch = torch_mod
+    x = torch.zeros((8, N), dtype=torch.int16, device="cuda")
+    xf = torch.zeros((8, N), dtype=torch.float32, device="cuda")
+    chain_cls(0).close()                                     # first use: the runtime's one-off allocations
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(120):
+        c = chain_cls(0)
+        c.set_overlap(1 + i % 3)
+        c.set_filter_mode(0x00)
+        c.process_q15(x)
+        c.process_f32(xf)
+        c.process_f32(x)
+        c.flush()
+        c.close()
+    torch.cuda.synchronize()
+    lost = free0 - torch.cuda.mem_get_info()[0]
+    assert lost < 64 * 1024 * 1024, f"{lost / 2**20:.0f} MiB not returned after 120 handles"
+
+
 def test_random_wide_cascades(ch, torch_mod, oracle):
     """Wide mode (0xA2): random Q2.14 cascades of 1..6 sections, any int16 tap (saturating accumulators make
     unstable ones well defined), both window modes, bit-exact against the integer model."""
