@@ -44,7 +44,8 @@ constexpr int kThreads = 256;
 constexpr int kLdsComplex = 16 * 272;                 // half-frame exchange image (4352 complex)
 constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 sections x 16 rows x float2
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
-constexpr int kLdsBytes = kSideOff + 16;              // two complex side slots
+constexpr int kLaneOff = kSideOff + 16;               // (two complex side slots) then the per-lane matrices P2^i: 6 x 16 x float4
+constexpr int kLdsBytes = kLaneOff + 6 * 16 * 16;
 
 // The two-component scan state travels as ONE register pair and every 2x2 matrix is stored column-major (a column is
 // an aligned register pair): a matrix-vector product is two packed FMAs, column x broadcast component -- for wave-uniform
@@ -359,7 +360,7 @@ __device__ __forceinline__ void pin_consts(const SecConsts &c)
 #endif
 template <bool PREDICT_NEXT, bool UNIT, int SIDX, typename SecT>
 __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const SecT &knext, const SecConsts c,
-                                            SecConsts &cn, const float4 lanep, float2 *scr_s, int lane, int wave,
+                                            SecConsts &cn, const float4 *lanep_lds, float2 *scr_s, int lane, int wave,
                                             v2f &zA, v2f &zB)
 {
     SA_STAMP_SEC(3);
@@ -401,6 +402,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     }
     if (row == 0) cst = v2f{0.f, 0.f};
     // start state of chunk A: row-local part + P2^i * (row start state); chunk B: Pc sA + zA
+    const float4 lanep = *lanep_lds;                     // read behind this section's barrier (the copy of section 0 is then visible)
     const v2f aS = mv_v(v2f{lanep.x, lanep.y}, v2f{lanep.z, lanep.w}, cst, e);
     const v2f bS = mv_s(c.pc0, c.pc1, aS, zA);
     // pole coordinates -> DF2T states of the recursion (sa_common.hpp), re-paired as (chunk A, chunk B)
@@ -448,7 +450,10 @@ __device__ __forceinline__ void iir_sections(v2f (&d)[32], const PlanT &ka, cons
                                              float2 *scr, int lane, int wave, v2f &zA, v2f &zB, const SecConsts c)
 {
     if constexpr (S < NSEC) {
-        const float4 lanep = *reinterpret_cast<const float4 *>(&lt->p[S][lane & 15][0]);
+        // the per-lane matrices sit in LDS (iir_cascade copies them once): a 64-bit global address per thread held through
+        // the whole cascade was among the values the tightest variants spilled
+        const float4 *lanep = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(scr) + (kLaneOff - kScrOff)) +
+                              16 * S + (lane & 15);
         SecConsts cn = c;
         iir_section<(S + 1 < NSEC), UNIT, S>(d, ka.sec[S], ka.sec[S + 1 < NSEC ? S + 1 : S], c, cn, lanep, scr + 16 * S, lane,
                                           wave, zA, zB);
@@ -460,6 +465,10 @@ template <int NSEC, bool UNIT, typename PlanT>
 __device__ __forceinline__ void iir_cascade(v2f (&d)[32], const PlanT &ka, const SaIirLaneTab *__restrict__ lt,
                                             float2 *scr, int t)
 {
+    // the per-lane matrices P2^i of all sections into LDS (96 x 16 bytes; read behind each section's scan barrier)
+    if (t < 16 * NSEC)
+        reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(scr) + (kLaneOff - kScrOff))[t] =
+            *reinterpret_cast<const float4 *>(&lt->p[t >> 4][t & 15][0]);
     // predictor for the first section (later ones run after the previous section's recursion)
     const SecConsts c0 = load_consts(ka.sec[0]);
     v2f tp[16];
@@ -884,9 +893,10 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const sa_in_t *_
     chain_frame<NSEC, UNIT, OUT, WINGEN>(in, SA_IN_SCALE_ARG out, f, smem, winb, twT, twB, twC, lanetab, ka);
 }
 
-// Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path).
+// Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path: two workgroups per CU are
+// asked for, so the register allocator has 256 registers and spills nothing in any instantiation).
 template <int NSEC, bool UNIT>
-__global__ __launch_bounds__(kThreads, 4) void time_f32_kernel(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM
+__global__ __launch_bounds__(kThreads, 2) void time_f32_kernel(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM
                                                                 float *__restrict__ out, int batch,
                                                                 const float4 *__restrict__ wint_plain,
                                                                 const SaIirLaneTab *__restrict__ lanetab,
