@@ -292,6 +292,11 @@ class GpuWorkload:
         out["config2_bypass_b256"] = {"frames_per_s": 256 / dt, "GBps": 256 * BYTES_PER_FRAME_F32 / dt / 1e9}
         dt = time_it(self.step, steps)
         out["bypass_b4096"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
+        if R > 3:                # the same with three launches in flight (the bypassed chain is not at the power cap)
+            ch.set_overlap(3)
+            dt = time_it(self.step, steps)
+            out["bypass_b4096_overlap3"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
+            ch.set_overlap(1)
         ch.reserve(B)
         for tag, lo, hi in (("", -2048, 2048), ("_fullscale", -32768, 32768)):
             xqs = [torch.randint(lo, hi, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
