@@ -3,7 +3,7 @@
 uploads, window modes and input scales through the Q15 path, bit-exact against the integer model every time;
 float chain on random batch sizes (float32 frames or int16 samples in) within tolerance.  Round 3: the launch mode changes at random (ordered, two or three
 launches in flight: sa_set_overlap), in overlap mode up to three calls are issued back to back before the flush, with control-plane
-calls between them.  usage: soak.py SECONDS [SEED]"""
+calls between them.  usage: soak.py SECONDS [SEED] [big]"""
 import os
 import sys
 import time
@@ -19,6 +19,10 @@ from oracle import oracle as orc  # noqa: E402
 N = 16384
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+# "big" as third argument: batches of hundreds to thousands of frames (workspace growth in flight, ragged last workgroups
+# of both integer cascades, many generations of workgroups per launch)
+BATCHES = ([300, 511, 513, 1000, 1023, 1025, 2047, 2049, 3000, 4095, 4096, 4097, 5000] if len(sys.argv) > 3 and sys.argv[3] == "big"
+           else [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 255, 257])
 ch = SpectrumChain(0)
 sos = np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"]
 t0 = time.time()
@@ -34,7 +38,7 @@ while time.time() - t0 < budget:
     burst = 1 if depth == 1 else int(rng.integers(1, 4))
     pending = []
     for _ in range(burst):
-        B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 255, 257]))
+        B = int(rng.choice(BATCHES))
         scale = int(rng.choice([16, 2048, 32768]))
         x = rng.integers(-scale, scale, size=(B, N)).astype(np.int16)
         cmd = int(rng.choice([0x00, 0xA1, 0xB1]))
@@ -59,7 +63,7 @@ while time.time() - t0 < budget:
             sys.exit(1)
         n_q15 += 1
     if n_q15 % 4 < burst:
-        Bf = int(rng.choice([1, 3, 8, 17, 64, 130]))
+        Bf = int(rng.choice([130, 257, 600, 1025] if len(BATCHES) == 13 else [1, 3, 8, 17, 64, 130]))
         xf = (rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.001, 0.2, (Bf, 1)) * np.arange(N))
               + 0.05 * rng.standard_normal((Bf, N))).astype(np.float32)
         ch.load_sos(sos)
