@@ -8,11 +8,17 @@ metric is quoted on).  Frames are independent, so ranks shard the batch dimensio
 data-path collective (weak scaling: 4096 frames per GPU); the only inter-rank traffic is the
 timing barrier / max-reduce, done over gloo on the host.
 
-Prints ONE JSON line on rank 0 with the driver's keys plus ``roofline`` and ``cpu_baseline``.
+Prints ONE JSON line on rank 0 with the driver's keys plus ``roofline`` and ``cpu_baseline``.  At N = 1 the line also
+carries ``configs``: the other single-GPU configurations of BASELINE.json (configs[1]: B = 256 fp32, IIR bypassed;
+configs[3]: B = 4096 Q15), each after the same conditioning as the headline, each with its own algorithmic bytes
+(131 072 / 98 304 B per frame) -- bounded to about three seconds; they are reported beside the headline and are never
+its ``value``.  ``host_us_per_call`` is the host time of one process call (Python + ctypes + launch), the only cost a
+batch-sharded run adds per rank.  Per-kernel times come from the launches' OWN start / stop events
+(``sa_set_profiling``, include/specan.h): they ride on the dispatch packets, so a kernel time cannot exceed its step.
 
 Headline mode: overlapped launches (``sa_set_overlap``, include/specan.h) -- ``--overlap D`` (default 2) keeps D
 launches of the handle in flight, so the tail of one batch runs under the head of the next (frames are
-independent: new/filter_iir12_cust.vhd:48-63 resets the state per frame).  The line says so
+independent: every frame starts from a zero filter state, SURVEY quirk Q5 / new/filter_iir_cust.vhd:142-146).  The line says so
 (``launches_in_flight``), its ``roofline`` is computed from the WALL time per step of the timed region (kernels
 overlap, so per-kernel event durations no longer add up), and the strictly stream-ordered figures -- wall and
 per-kernel HIP events, the number a ``rocprofv3 --kernel-trace`` of ``--overlap 1`` reproduces -- are kept beside
@@ -207,6 +213,9 @@ class StubDevice:
     def kernel_ms(self, steps):
         return [2.0 * (1 + self.rank)] * steps
 
+    def host_us_per_call(self, n=8):
+        return 10.0 * (1 + self.rank)
+
     def close(self):
         pass
 
@@ -259,16 +268,99 @@ class GpuWorkload:
         self.torch.cuda.synchronize(self.dev)
 
     def kernel_ms(self, steps):
-        """HIP events around each launch, recorded on the stream the kernel is launched on (torch's current
-        stream of this device is the one handed to the C ABI)."""
-        torch = self.torch
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for e0, e1 in evs:
-            e0.record()
+        """Device time of each of `steps` back-to-back stream-ordered launches, from the launch's own start / stop events
+        (sa_set_profiling: hipExtLaunchKernel binds them to the dispatch packet -- no marker packets, the train runs as
+        it does untimed; the launch stream is torch's current stream of this device, handed to the C ABI)."""
+        self.ch.set_profiling(steps)
+        for _ in range(steps):
             self.step()
-            e1.record()
+        ms = self.ch.profile_read(steps)
+        self.ch.set_profiling(0)
+        return ms
+
+    def host_us_per_call(self, n=64):
+        """Host time of one process call (Python wrapper + ctypes + launch) while the GPU is still busy with the calls
+        before it: n calls in a row without a wait in between (n x 128 us of device work against well under a
+        millisecond of host work, so the queue never fills)."""
         self.sync()
-        return [e0.elapsed_time(e1) for e0, e1 in evs]
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.step()
+        dt = time.perf_counter() - t0
+        self.sync()
+        return dt / n * 1e6
+
+    def _measure(self, fn, frames, bytes_per_frame, steps, depth, timed_calls=True):
+        """One configuration: `depth` launches in flight, 0.25 s of untimed conditioning (as the headline gets), then
+        `steps` steps between two synchronisations; in the ordered mode also the device time of every call."""
+        ch = self.ch
+        ch.set_overlap(depth)
+        if depth == 1 and timed_calls:
+            ch.set_profiling(steps)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.25:
+            for _ in range(10):
+                fn()
+            self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.sync()
+        dt = (time.perf_counter() - t0) / steps
+        res = {"frames_per_s": round(frames / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+               "achieved_GBps": round(frames * bytes_per_frame / dt / 1e9, 1),
+               "frac": round(frames * bytes_per_frame / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        if depth == 1 and timed_calls:
+            ms = ch.profile_read(steps)
+            ch.set_profiling(0)
+            res["call_ms_avg"] = round(float(np.mean(ms)), 4)
+            res["call_frac"] = round(frames * bytes_per_frame / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        ch.set_overlap(1)
+        return res
+
+    def configs(self):
+        """The other single-GPU configurations of BASELINE.json, in the default line (the driver passes no flag).
+        configs[1]: B = 256 fp32 frames, Hann + FFT + magnitude, IIR bypassed -- the board's power-on mode
+        (new/command_control.vhd:31); 64 rotating 256-frame slices of the headline's buffers (1 GiB in, 1 GiB out: a
+        handful of slices would live in the 256 MB Infinity Cache).  configs[3]: B = 4096 int16 frames, 12-bit samples,
+        FPGA-exact window + default ALPHA / BETA cascade + SA-FXFFT-1, ordered and with two launches in flight."""
+        torch, ch, dev, B, R, gen = self.torch, self.ch, self.dev, self.B, self.R, self.gen
+        out = {}
+        nb = 256
+        slices = [(x[j:j + nb], o[j:j + nb]) for x, o in zip(self.xs, self.outs) for j in range(0, B - nb + 1, nb)]
+        k = [0]
+
+        def step256():
+            x, o = slices[k[0] % len(slices)]
+            k[0] += 1
+            ch.process_f32(x, out=o)
+        ch.set_filter_mode(0xB1)
+        if slices:
+            r = self._measure(step256, nb, BYTES_PER_FRAME_F32, 200, 1)
+            r["bytes_per_frame"] = BYTES_PER_FRAME_F32
+            r["workload"] = "BASELINE.json configs[1]: batch=256 x 16K fp32, Hann + 16K FFT + magnitude, IIR bypassed, stream-ordered"
+            out["config2_b256_bypass"] = r
+        ch.set_filter_mode(0xA1)
+        xqs = [torch.randint(-2048, 2048, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+               for _ in range(R)]
+        oqs = [torch.empty((B, N, 2), dtype=torch.int16, device=dev) for _ in range(R)]
+        ch.reserve(B)
+
+        def qstep():
+            ch.process_q15(xqs[k[0] % R], out=oqs[k[0] % R])
+            k[0] += 1
+        ch.set_filter_mode(0x00)
+        r = self._measure(qstep, B, BYTES_PER_FRAME_Q15, 30, 1)
+        r["bytes_per_frame"] = BYTES_PER_FRAME_Q15
+        r["workload"] = (f"BASELINE.json configs[3]: batch={B} x 16K int16 (12-bit samples), FPGA-exact window + default "
+                         f"ALPHA/BETA cascade + fixed-point FFT, IQ frames out; call = cascade kernel + FFT kernel")
+        if R > 2:
+            r["overlap2"] = self._measure(qstep, B, BYTES_PER_FRAME_Q15, 40, 2)
+            ch.reserve(B)
+        out["config4_q15_default"] = r
+        ch.set_filter_mode(0xA1)
+        del xqs, oqs
+        return out
 
     def extras(self, steps):
         """Bypass (config 2) and Q15 (config 4) figures next to the headline; not the bench line's value."""
@@ -298,6 +390,9 @@ class GpuWorkload:
             out["bypass_b4096_overlap3"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
             ch.set_overlap(1)
         ch.reserve(B)
+        g4 = np.load(os.path.join(ROOT, "tests", "golden", "g4_q15_frames.npz"))
+        ch.load_sos_q14(g4["sos_q14"])           # the Q2.14 quantisation of the headline's 12th-order Butterworth
+        ch.load_coeffs_q7(g4["c_gui"])           # the GUI's default upload (B1 != 0: the nine-instruction step)
         for tag, lo, hi in (("", -2048, 2048), ("_fullscale", -32768, 32768)):
             xqs = [torch.randint(lo, hi, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
                    for _ in range(R)]
@@ -307,10 +402,18 @@ class GpuWorkload:
             def qstep():
                 ch.process_q15(xqs[k[0] % R], out=oqs[k[0] % R])
                 k[0] += 1
-            for name, cmd in (("config4_q15_default_iir", 0x00), ("q15_bypass", 0xB1)):
+            for name, cmd in (("config4_q15_default_iir", 0x00), ("q15_bypass", 0xB1), ("q15_wide_6sec", 0xA2),
+                              ("q15_gui_upload_9instr", 0xA1)):
                 ch.set_filter_mode(cmd)
                 dt = time_it(qstep, 5)
                 out[name + tag] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+            if R > 2:              # the wide cascade (0xA2, all six designed sections in Q2.14) with two launches in flight
+                ch.set_overlap(2)
+                ch.reserve(B)
+                ch.set_filter_mode(0xA2)
+                dt = time_it(qstep, 12)
+                out["q15_wide_6sec" + tag + "_overlap2"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
+                ch.set_overlap(1)
             for depth in (2, 3):   # config 4 with launches in flight: the FFT of batch k under the filter of batch k+1
                 if R <= depth:
                     continue
@@ -346,24 +449,85 @@ class GpuWorkload:
         self.ch.close()
 
 
+def _sysfs_card(torch, dev_index):
+    """sysfs device directory of the card behind HIP device `dev_index` (matched by PCI address), or None."""
+    import glob
+    bdf = None
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:                                                  # noqa: BLE001  (older torch: no PCI fields)
+        pass
+    amd = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                continue
+        except OSError:
+            continue
+        if bdf and os.path.basename(os.path.realpath(d)).lower() == bdf:
+            return d
+        amd.append(d)
+    return amd[0] if (bdf is None and len(amd) == 1) else None
+
+
+def _read_power_sysfs(card):
+    """(socket W, cap W, sclk MHz) from hwmon / pp_dpm_sclk of one card; raises when the layout is not there."""
+    import glob
+    hw = glob.glob(os.path.join(card, "hwmon", "hwmon*"))[0]
+    try:
+        w = float(open(os.path.join(hw, "power1_average")).read()) / 1e6
+    except OSError:
+        w = float(open(os.path.join(hw, "power1_input")).read()) / 1e6
+    cap = float(open(os.path.join(hw, "power1_cap")).read()) / 1e6
+    mhz = None
+    for ln in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines():
+        if ln.strip().endswith("*"):
+            mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+    if mhz is None:
+        raise OSError("no current level in pp_dpm_sclk")
+    return w, cap, mhz
+
+
 def power_sample(wl, dev_index, seconds):
-    """Socket power and shader clock of the card while wl.step() runs back to back for `seconds` (untimed)."""
+    """Socket power and shader clock of the card while wl.step() runs back to back for `seconds` (untimed).  Read in
+    process from sysfs (hwmon power1_average, pp_dpm_sclk).  Only when sysfs does not have them a `rocm-smi` child is
+    tried -- never under a profiler (ROCP* / LD_PRELOAD in the environment: rocm-smi is a `#!/usr/bin/env python3`
+    script, i.e. an exec hop inside a GPU-initialised, profiler-preloaded process tree), and with those variables
+    stripped from the child's environment."""
     import subprocess
     import threading
     shots, stop = [], threading.Event()
+    card = _sysfs_card(wl.torch, dev_index)
+    source = ["sysfs hwmon power1_average / pp_dpm_sclk"]
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) or k == "LD_PRELOAD" for k in os.environ)
+
+    def one_shot():
+        if card is not None:
+            try:
+                return _read_power_sysfs(card)
+            except (OSError, ValueError, IndexError):
+                pass
+        if profiled:
+            return None
+        env = {k: v for k, v in os.environ.items() if not (k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS")) or k == "LD_PRELOAD")}
+        r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                           capture_output=True, text=True, timeout=10, env=env)
+        c = next(iter(json.loads(r.stdout).values()))
+        source[0] = "rocm-smi"
+        return (float(c["Current Socket Graphics Package Power (W)"]), float(c["Max Graphics Package Power (W)"]),
+                float(c["sclk clock speed:"].strip("()").lower().replace("mhz", "")))
 
     def watch():
         while not stop.is_set():
             try:
-                r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showpower", "--showclocks", "--showmaxpower",
-                                    "--json"], capture_output=True, text=True, timeout=10)
-                card = next(iter(json.loads(r.stdout).values()))
-                shots.append((float(card["Current Socket Graphics Package Power (W)"]),
-                              float(card["Max Graphics Package Power (W)"]),
-                              float(card["sclk clock speed:"].strip("()").lower().replace("mhz", ""))))
+                v = one_shot()
             except Exception:                                          # noqa: BLE001  (tool missing, other layout)
                 return
-            stop.wait(0.2)
+            if v is None:
+                return
+            shots.append(v)
+            stop.wait(0.1)
     th = threading.Thread(target=watch, daemon=True)
     th.start()
     t0 = time.perf_counter()
@@ -378,8 +542,8 @@ def power_sample(wl, dev_index, seconds):
         return None
     w = sorted(x[0] for x in shots)
     f = sorted(x[2] for x in shots)
-    return {"socket_w": w[len(w) // 2], "cap_w": shots[0][1], "sclk_mhz": f[len(f) // 2], "samples": len(shots),
-            "source": "rocm-smi during an untimed repeat of the headline step loop"}
+    return {"socket_w": round(w[len(w) // 2], 1), "cap_w": shots[0][1], "sclk_mhz": f[len(f) // 2], "samples": len(shots),
+            "source": source[0] + " during an untimed repeat of the headline step loop"}
 
 
 def main():
@@ -395,7 +559,9 @@ def main():
                     help="launches of the handle kept in flight in the timed region (sa_set_overlap; 1 = strictly "
                          "stream-ordered, which is also measured and reported under 'ordered')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
+    ap.add_argument("--no-power", action="store_true", help="skip the power / clock sample")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (BASELINE.json configs[1] and configs[3] beside the headline; N = 1 only)")
     ap.add_argument("--extras", action="store_true", help="also time the bypass (config 2) and Q15 (config 4) paths")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -489,10 +655,20 @@ def main():
     k_avg_ms = float(np.mean(k_ms))
     k_med_ms = float(k_ms[len(k_ms) // 2])
     per_rank_kernel_ms = gather_floats(k_avg_ms, world)                  # launch skew between GPUs, if any
+    # host cost of one process call, ordered and in the headline mode: with independent frames and no collective it
+    # is the only thing a rank adds per step, i.e. what weak scaling over GPUs depends on (MAX over ranks)
+    host_us_ord = max(gather_floats(wl.host_us_per_call(), world))
+    wl.set_overlap(a.overlap)
+    host_us_head = max(gather_floats(wl.host_us_per_call(), world)) if a.overlap > 1 else host_us_ord
+    wl.set_overlap(1)
+
+    # the other single-GPU configurations of BASELINE.json, beside the headline in the default line, BEFORE the power
+    # sample (2.5 s at the cap leave the chip hotter than the headline found it)
+    configs = wl.configs() if (world == 1 and rank == 0 and not stub and not a.no_configs) else {}
 
     # Package power and shader clock while the headline mode runs (untimed repeat of the step loop, rank 0's card only):
     # the launch sits at the power cap and the clock is what gives (profiles/r3_power_clock.txt), which is what bounds
-    # the roofline fraction of this arithmetic.  rocm-smi reads sysfs from a side thread; null when it is not there.
+    # the roofline fraction of this arithmetic.  A side thread reads sysfs (hwmon); null when it is not there.
     power = None
     if rank == 0 and not stub and not a.no_power:
         wl.set_overlap(a.overlap)
@@ -545,6 +721,9 @@ def main():
                        "launch_mode": (f"sa_set_overlap({a.overlap}): results of a call visible after the next "
                                        f"{a.overlap - 1} call(s) or sa_flush" if a.overlap > 1 else "stream-ordered")},
             "per_rank_kernel_ms": [round(v, 4) for v in per_rank_kernel_ms],
+            "host_us_per_call": {"ordered": round(host_us_ord, 2), "headline_mode": round(host_us_head, 2),
+                                 "note": "host time of one process call (Python + ctypes + launch), MAX over ranks; the "
+                                         "only per-step cost a rank adds: frames are independent, no collective"},
         }
         if not stub:
             line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -552,7 +731,7 @@ def main():
                                 "traffic_source": traffic_src,
                                 "basis": (f"wall ms_per_step of the timed region, {a.overlap} launches in flight "
                                           f"(per-kernel durations overlap)" if a.overlap > 1
-                                          else "per-launch HIP events on the launch stream"),
+                                          else "the launches' own start / stop events (sa_set_profiling)"),
                                 "kernel": wl.kernel_name, "kernel_ms_avg": round(k_avg_ms, 4),
                                 "kernel_ms_median": round(k_med_ms, 4),
                                 "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME_F32,
@@ -563,7 +742,10 @@ def main():
             line["ordered"] = {"value": round(fps_ord, 1), "ms_per_step": round(elapsed_ord / a.steps * 1e3, 4),
                                "kernel_ms_avg": round(k_avg_ms, 4), "achieved": round(achieved_ord, 1),
                                "frac": round(achieved_ord / HBM_PEAK_GBS, 4),
-                               "basis": "strictly stream-ordered launches; per-launch HIP events on the launch stream"}
+                               "basis": "strictly stream-ordered launches; kernel time = the launch's own start / stop "
+                                        "events on its dispatch packet (sa_set_profiling), as rocprofv3 --kernel-trace sees it"}
+            if configs:
+                line["configs"] = configs
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if extras:

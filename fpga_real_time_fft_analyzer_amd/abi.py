@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
     L.sa_get_overlap.argtypes = [H, C.POINTER(C.c_int)]
     L.sa_debug_overlap_streams.argtypes = [H, C.c_void_p, C.POINTER(C.c_int)]
     L.sa_flush.argtypes = [H, C.c_void_p]
+    L.sa_set_profiling.argtypes = [H, C.c_int]
+    L.sa_profile_read.argtypes = [H, C.POINTER(C.c_float), C.c_int]
     L.sa_set_filter_mode.argtypes = [H, C.c_uint8]
     L.sa_get_filter_mode.argtypes = [H, C.POINTER(C.c_uint8)]
     L.sa_load_coeffs_q7.argtypes = [H, C.POINTER(C.c_int8)]
@@ -98,7 +100,7 @@ def lib() -> C.CDLL:
     L.sa_debug_iir_plan_f32.argtypes = [H, C.POINTER(C.c_float), C.c_int]
     L.sa_iir_plan_from_sos.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.c_int]
     for name in ("sa_create", "sa_destroy", "sa_abi_version", "sa_reserve", "sa_set_overlap", "sa_get_overlap",
-                 "sa_debug_overlap_streams", "sa_flush", "sa_set_filter_mode",
+                 "sa_debug_overlap_streams", "sa_flush", "sa_set_profiling", "sa_profile_read", "sa_set_filter_mode",
                  "sa_get_filter_mode", "sa_load_coeffs_q7", "sa_get_coeffs_q7", "sa_feed_command_bytes",
                  "sa_feed_command_bytes_ex", "sa_get_transport",
                  "sa_load_sos_f32", "sa_load_sos_f64", "sa_load_sos_q14", "sa_set_window_q15",

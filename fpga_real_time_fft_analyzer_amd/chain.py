@@ -8,6 +8,7 @@ PyTorch is used only for device memory and streams.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -44,6 +45,14 @@ class SpectrumChain:
 
     Not thread-safe (same rule as the C ABI).  All process calls are asynchronous on the current
     torch stream of the handle's device.
+
+    Overlap mode (:meth:`set_overlap` with depth d > 1): a call runs on an internal stream of the library that torch's
+    caching allocator knows nothing about, and the C contract lends the call's input and output tensors to the library
+    until d-1 further calls have been made or :meth:`flush` is called.  The wrapper therefore keeps a reference to the
+    tensors of the last d-1 calls (a temporary passed as input, or a result that is dropped, would otherwise be
+    recycled by the allocator under the running kernel) and releases them at the join, in :meth:`flush` and in
+    :meth:`set_overlap`.  A result returned by a process call in this mode holds valid data on the current stream
+    only after those d-1 further calls or after :meth:`flush`.
     """
 
     def __init__(self, device: Optional[int | torch.device | str] = None):
@@ -60,6 +69,8 @@ class SpectrumChain:
             raise SpecanError(rc, self._lib.sa_last_error(None).decode())
         self._h = h
         self.control_generation = 0        # bumped by every call that changes what the path computes (virtual_fpga.py)
+        self._depth = 1                    # launches in flight (sa_set_overlap)
+        self._lent = collections.deque()   # (input, output) of the overlapped calls the caller's stream has not joined
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
@@ -73,8 +84,16 @@ class SpectrumChain:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.sa_destroy(self._h)
+            self._lib.sa_destroy(self._h)        # waits on the host for the handle's own work
             self._h = None
+            self._lent.clear()
+
+    def _lend(self, x: torch.Tensor, out: torch.Tensor):
+        """Overlap mode: the call just made owns (x, out) until depth-1 further calls have been made."""
+        if self._depth > 1:
+            self._lent.append((x, out))
+            while len(self._lent) > self._depth - 1:   # this call enqueued the join of the call made depth-1 calls ago
+                self._lent.popleft()
 
     def __del__(self):
         try:
@@ -208,8 +227,11 @@ class SpectrumChain:
     def set_overlap(self, depth: int):
         """Opt-in overlapped launches (include/specan.h, sa_set_overlap): with depth d > 1 the results of a
         process call are visible on the current stream after d-1 further calls or after :meth:`flush`, and the
-        call's input and output tensors belong to the library until then.  1 = strictly stream-ordered."""
+        call's input and output tensors belong to the library until then (the wrapper holds them: class docstring).
+        1 = strictly stream-ordered."""
         self._check(self._lib.sa_set_overlap(self._h, int(depth)))
+        self._depth = int(depth)                 # a change of depth waited on the host for everything in flight
+        self._lent.clear()
 
     @property
     def overlap(self) -> int:
@@ -227,6 +249,20 @@ class SpectrumChain:
     def flush(self):
         """Make the current stream wait for every outstanding overlapped call (no host wait)."""
         self._check(self._lib.sa_flush(self._h, self._stream()))
+        self._lent.clear()
+
+    def set_profiling(self, ring: int):
+        """Launch timing (include/specan.h, sa_set_profiling): keep the device times of the last ``ring`` stream-ordered
+        process calls (0 = off).  The events ride on the dispatch packets; a train of calls runs as it does untimed."""
+        self._check(self._lib.sa_set_profiling(self._h, int(ring)))
+
+    def profile_read(self, n: int) -> list:
+        """Device time in ms of up to ``n`` of the most recent timed calls, oldest first (waits for them)."""
+        buf = (C.c_float * max(1, int(n)))()
+        got = self._lib.sa_profile_read(self._h, buf, int(n))
+        if got < 0:
+            self._check(got)
+        return [float(buf[i]) for i in range(got)]
 
     def iir_plan(self) -> np.ndarray:
         n = self._lib.sa_debug_iir_plan_f32(self._h, None, 0)
@@ -263,6 +299,7 @@ class SpectrumChain:
         else:
             self._check(self._lib.sa_process_f32(self._h, x.data_ptr(), out.data_ptr(), B, _OUT_KINDS[out_kind],
                                                  self._stream()))
+        self._lend(x, out)
         return out
 
     def process_q15(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -274,6 +311,7 @@ class SpectrumChain:
         elif tuple(out.shape) != shape or out.dtype != torch.int16 or out.device != self.device or not out.is_contiguous():
             raise SpecanError(abi.SA_ESHAPE, f"out must be a contiguous int16 tensor of shape {shape}")
         self._check(self._lib.sa_process_q15(self._h, x.data_ptr(), out.data_ptr(), B, self._stream()))
+        self._lend(x, out)
         return out
 
     def filter_q15(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -284,10 +322,14 @@ class SpectrumChain:
         elif tuple(out.shape) != (B, SA_N) or out.dtype != torch.int16 or out.device != self.device or not out.is_contiguous():
             raise SpecanError(abi.SA_ESHAPE, "out must be a contiguous int16 [B,16384] tensor")
         self._check(self._lib.sa_filter_q15(self._h, x.data_ptr(), out.data_ptr(), B, self._stream()))
+        self._lend(x, out)
         return out
 
     def frames_bytes(self, iq: torch.Tensor) -> list[bytes]:
-        """Device IQ tensor -> list of 65536-byte frames exactly as sequ2 emits them."""
+        """Device IQ tensor -> list of 65536-byte frames exactly as sequ2 emits them.  In overlap mode the current
+        stream first joins the outstanding calls (the tensor may be the result of one of them)."""
+        if self._depth > 1:
+            self.flush()
         host = iq.detach().to("cpu").contiguous().numpy().astype("<i2", copy=False)
         return [host[i].tobytes() for i in range(host.shape[0])]
 

@@ -964,7 +964,7 @@ namespace {
 
 template <int NSEC, bool UNIT>
 hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int batch, int out_kind, const SaF32Tables &tb,
-                       const SaIirK &ka, hipStream_t stream, hipEvent_t stop)
+                       const SaIirK &ka, hipStream_t stream, SaLaunchEv ev)
 {
     const dim3 grid(batch), block(kThreads);
     hipError_t e = hipSuccess;
@@ -974,7 +974,7 @@ hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int b
                               : chain_f32_kernel<NSEC, UNIT, OUTK, false>;                             \
         e = set_lds(kern);                                                                             \
         if (e != hipSuccess) return e;                                                                 \
-        hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, SA_IN_SCALE_ARG out, batch, tb.win_b, tb.twT, \
+        hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, ev.start, ev.stop, 0, in, SA_IN_SCALE_ARG out, batch, tb.win_b, tb.twT, \
                            tb.twB, tb.twC, tb.lanetab, ka);                                            \
     } while (0)
     switch (out_kind) {
@@ -985,7 +985,7 @@ hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int b
             auto kern = time_f32_kernel<NSEC, UNIT>;
             e = set_lds(kern);
             if (e != hipSuccess) return e;
-            hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, nullptr, stop, 0, in, SA_IN_SCALE_ARG reinterpret_cast<float *>(out), batch,
+            hipExtLaunchKernelGGL(kern, grid, block, kLdsBytes, stream, ev.start, ev.stop, 0, in, SA_IN_SCALE_ARG reinterpret_cast<float *>(out), batch,
                                tb.win_t, tb.lanetab, ka);
             break;
         }
@@ -1000,10 +1000,10 @@ hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int b
 // tb.iir->nsec is the PADDED section count (0, 2, 4 or 6; see build_plan in specan_abi.cpp).
 #if SA_F32_INPUT_I16
 hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &tb,
-                                   hipStream_t stream, hipEvent_t stop)
+                                   hipStream_t stream, SaLaunchEv ev)
 #else
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
-                               hipStream_t stream, hipEvent_t stop)
+                               hipStream_t stream, SaLaunchEv ev)
 #endif
 {
 #if !SA_F32_INPUT_I16
@@ -1015,13 +1015,13 @@ hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_ki
     const SaIirK &ka = nsec > 0 ? *tb.iir : kNoIir;
     const bool unit = nsec > 0 && ka.unit != 0;
     switch (nsec) {
-        case 0: return launch_nsec<0, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
-        case 2: return unit ? launch_nsec<2, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<2, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
-        case 4: return unit ? launch_nsec<4, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<4, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
-        case 6: return unit ? launch_nsec<6, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch_nsec<6, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, stop);
+        case 0: return launch_nsec<0, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev);
+        case 2: return unit ? launch_nsec<2, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch_nsec<2, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev);
+        case 4: return unit ? launch_nsec<4, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch_nsec<4, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev);
+        case 6: return unit ? launch_nsec<6, true>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch_nsec<6, false>(in, in_scale, out, batch, out_kind, tb, ka, stream, ev);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,11 +1,12 @@
 // chain_q15.hip -- bit-exact integer signal path for gfx950 (MI355X).
 //
-//   sa_filter kernel : Q15 window (new/hann8192.vhd:36-39) + 6-stage integer biquad cascade
-//                      (new/filter_iir_cust.vhd:96-117, new/filter_iir12_cust.vhd:68-240).
-//                      The recursion is non-linear (per-product truncation, 16-bit wrap), so a
-//                      frame cannot be cut in time; the parallelism is batch x section: 8 lanes
-//                      per frame run the six sections as a systolic pipeline (lane s works on
-//                      sample n-s), neighbours hand samples over with a wave shuffle.
+//   cascade kernels  : Q15 window (new/hann8192.vhd:36-39) + 6-stage integer biquad cascade, in the FPGA-exact Q7
+//                      form (filter_q7_kernel: new/filter_iir_cust.vhd:96-117, new/filter_iir12_cust.vhd:68-240) and
+//                      in the wide Q2.14 form (filter_w14_kernel: six independent sections, the build's own spec,
+//                      oracle/specan_oracle.c:or_iir_sos_q14).  Both recursions are non-linear (per-product
+//                      truncation and 16-bit wrap; rounding and saturation), so a frame cannot be cut in
+//                      time; the parallelism is batch x section: one frame per 16-lane DPP row, the six sections a
+//                      systolic pipeline along the lanes (lane s works on sample n-s).
 //   sa_fft kernel    : SA-FXFFT-1, the fixed-point FFT that stands where ip/xfft_0 stands
 //                      (radix-4 DIF, >>2 per stage, Q15 twiddles, truncation).  One 256-thread
 //                      workgroup per frame, data in LDS as packed (re,im) int16 pairs, Stockham
@@ -85,99 +86,26 @@ constexpr int kTile = SA_Q15_TILE;    // samples per staging tile
 constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
-constexpr int kFramesPerWave = 4;      // one frame per 16-lane row: lane 0..5 of the row = section 0..5
+#ifndef SA_Q15_FPW
+#define SA_Q15_FPW 4
+#endif
+constexpr int kFramesPerWave = SA_Q15_FPW;   // one frame per 16-lane row (rows beyond it idle: A/B builds with 2)
 // moving a tile between memory and LDS: 16 bytes (8 samples) per lane, kTile / 8 lanes per frame row
 constexpr int kTileLanes = kTile / 8;                       // lanes that cover one row of a tile (32; 16 for 128-sample tiles)
-constexpr int kTileRows = 64 / kTileLanes;                  // rows a wave covers per pass
-constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's four frames
+constexpr int kTileRows = (64 / kTileLanes) < kFramesPerWave ? (64 / kTileLanes) : kFramesPerWave;   // rows a wave covers per pass
+constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's frames
+constexpr bool kTileAllLanes = kTileRows * kTileLanes == 64;   // false only in A/B builds with fewer frames per wave than rows per pass
 static_assert(kTile % 32 == 0 && kTileLanes <= 64 && kTileRows * kTilePasses == kFramesPerWave, "tile geometry");
+__device__ __forceinline__ bool tile_lane_on(int lane) { return kTileAllLanes || lane / kTileLanes < kTileRows; }
 
-// full-rate 24-bit multiply-add (samples are 16-bit, taps 8-bit); the compiler otherwise falls back to
-// the quarter-rate v_mul_lo_u32 for some of the products
-__device__ __forceinline__ int mad_i24(int a, int b, int c)
-{
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// one biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
+// One biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
 //   y = B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum
 //   taken modulo 2^16 (wrapping each term first gives the same residue).
 // The two subtracted terms use -floor(v/128) = floor((-v + 127)/128), so all five terms add.
 // The taps are held pre-shifted by 9: floor(c v / 128) mod 2^16 is then bits 16..31 of the 32-bit product
 // v * (c << 9) (exact: only bits above 31 are lost), i.e. its high word, which the SDWA form of v_add_u32
 // reads in place -- no shift instructions -- and whose last add sign-extends the 16-bit result on write.
-// 5 multiplies + 4 adds per step; the feedback path y[n-1] -> y[n] is two instructions long.
-__device__ __forceinline__ int mul_i24(int a, int b)
-{
-    int r;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ int add_hi_hi(int a, int b)          // hi16(a) + hi16(b)
-{
-    int r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
-        : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ int add_acc_hi(int acc, int b)       // acc + hi16(b)
-{
-    int r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-        : "=v"(r) : "v"(acc), "v"(b));
-    return r;
-}
-__device__ __forceinline__ int add_acc_hi_sext16(int acc, int b)   // (int16)(acc + hi16(b))
-{
-    int r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:WORD_1"
-        : "=v"(r) : "v"(acc), "v"(b));
-    return r;
-}
-
-struct BiqQ7 {
-    int cB0, cB1, cB2, nA0, nA1;            // taps << 9; nA* = -A* << 9
-    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
-    __device__ __forceinline__ void set(int b0, int b1, int b2, int a0, int a1)
-    {
-        cB0 = b0 << 9; cB1 = b1 << 9; cB2 = b2 << 9; nA0 = -(a0 << 9); nA1 = -(a1 << 9);
-    }
-    __device__ __forceinline__ int step(int x)
-    {
-        const int k127 = 127 << 9;
-        const int p1 = mul_i24(x1, cB1);
-        const int p2 = mul_i24(x2, cB0);
-        const int p3 = mad_i24(y2, nA0, k127);
-        const int p0 = mul_i24(x, cB2);
-        const int p4 = mad_i24(y1, nA1, k127);
-        int s = add_hi_hi(p1, p2);
-        s = add_acc_hi(s, p3);
-        s = add_acc_hi(s, p0);
-        const int y = add_acc_hi_sext16(s, p4);
-        x2 = x1; x1 = x;
-        y2 = y1; y1 = y;
-        return y;
-    }
-};
-
-// wide mode (build spec, oracle/specan_oracle.c:or_iir_sos_q14): Q2.14 taps, 64-bit accumulator,
-// round-half-up shift by 14, saturation
-struct BiqQ14 {
-    int b0, b1, b2, a1, a2;
-    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
-    __device__ __forceinline__ int step(int x)
-    {
-        long long acc = (long long)b0 * x + (long long)b1 * x1 + (long long)b2 * x2 - (long long)a1 * y1 -
-                        (long long)a2 * y2;
-        acc = (acc + 8192) >> 14;
-        acc = acc > 32767 ? 32767 : (acc < -32768 ? -32768 : acc);
-        x2 = x1; x1 = x;
-        y2 = y1; y1 = (int)acc;
-        return (int)acc;
-    }
-};
+// The products are v_mul_i32_i24 / v_mad_i32_i24 (full rate; samples are 16-bit, shifted taps 17-bit).
 
 // window + stage one tile of 8 frames x 256 samples into LDS (16 B per lane, two rows per instruction)
 struct Q15TileRegs {
@@ -195,7 +123,7 @@ __device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, co
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
         r.x[i] = make_uint4(0, 0, 0, 0);
-        if (f < batch) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
+        if (f < batch && tile_lane_on(lane)) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
         r.c[i] = *reinterpret_cast<const uint4 *>(rom + n0 + col);
     }
 }
@@ -219,7 +147,7 @@ __device__ __forceinline__ void q15_store_tile(const Q15TileRegs &r, int16_t (*t
                 a = win_u16(lo16(xs[k]), lo16(cs[k]));
                 b = win_u16(hi16(xs[k]), hi16(cs[k]));
             }
-            *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
+            if (tile_lane_on(lane)) *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
         }
     }
 }
@@ -242,6 +170,7 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
         const int row = kTileRows * i + lane / kTileLanes;
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
+        if (!tile_lane_on(lane)) continue;
         const int sc = (src_col + col) & col_mask;      // 8-sample chunks: a ring wraps between chunks only
         uint4 ov;
         ov.x = *reinterpret_cast<const unsigned *>(&src[row][sc + 0]);
@@ -252,96 +181,20 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
     }
 }
 
-// One wave = 4 frames, one per 16-lane row.  Lane `sec` of a row runs section `sec`; at global step T it
-// works on sample T - sec.  The body is unconditional: before the frame starts every section sees zeros
-// from a zero state (which leaves the state zero), after it ends the extra outputs are not stored.
-// The neighbour hand-off is a DPP row shift whose out-of-row case (lane 0 = section 0) keeps the `old`
-// operand, which holds the next input sample: no select.  Section 0 takes its inputs eight at a time
-// from LDS, so no LDS latency sits on the serial chain.  With 4096 frames that is 1024 waves, one per
-// SIMD of the chip; the chain is serial in time, so lanes, not waves, are what is left idle.  (Two frames per
-// wave -- twice the waves, half of each idle -- measured 1.3x slower: a single wave already issues one
-// dependent instruction per ~7 cycles, two waves per SIMD reach ~4.7, but each carries half the frames.)
-template <bool WIDE>
-__global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restrict__ in,
-                                                         int16_t *__restrict__ out, int batch, SaQ15Params prm,
-                                                         const int16_t *__restrict__ rom)
+// Window only (filter mode 0xB1 through sa_filter_q15: the windowed time series, new/hann8192.vhd:36-39): one wave =
+// 4 frames, a tile at a time through LDS.
+__global__ __launch_bounds__(64) void window_q15_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, int batch,
+                                                         SaQ15Params prm, const int16_t *__restrict__ rom)
 {
     __shared__ __attribute__((aligned(16))) int16_t tin[kFramesPerWave][kRowPitch];
-    __shared__ __attribute__((aligned(16))) int16_t ring[kFramesPerWave][kRingPitch];
     const int lane = threadIdx.x;
-    const int fr = lane >> 4;           // frame slot in this wave
-    const int sec = lane & 15;          // section index (6..15 idle)
     const int f0 = blockIdx.x * kFramesPerWave;
-    SA_Q15_STAMP_BEGIN(blockIdx.x);
-
-    if (prm.filter == SA_FILTER_NONE) {            // window only
-        for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
-            q15_stage_tile(in, rom, tin, f0, batch, n0, lane, prm.win_mode);
-            __syncthreads();
-            q15_flush_tile<kRowPitch>(out, tin, 0, f0, batch, n0, lane);
-            __syncthreads();
-        }
-        return;
-    }
-
-    using Biq = typename std::conditional<WIDE, BiqQ14, BiqQ7>::type;
-    Biq bq{};
-    // Lanes 0..5 (or 0..nsec-1) of the row run the real sections; lanes up to 8 run identity sections so
-    // that the output appears at lane 8 with a delay of exactly 8 steps: every group of 8 steps then
-    // delivers 8 consecutive, 16-byte aligned samples -> one ds_write_b128 instead of 8 short stores.
-    const int nreal = WIDE ? prm.nsec_wide : 6;
-    if constexpr (WIDE) {
-        if (sec < nreal) {
-            const int16_t *c = &prm.sos_q14[sec * 6];
-            bq.b0 = c[0]; bq.b1 = c[1]; bq.b2 = c[2]; bq.a1 = c[4]; bq.a2 = c[5];
-        } else {
-            bq.b0 = 16384; bq.b1 = bq.b2 = bq.a1 = bq.a2 = 0;      // (16384 x + 8192) >> 14 = x exactly
-        }
-    } else {
-        if (sec < nreal) {
-            const int8_t *c = &prm.c12[(sec & 1) ? 6 : 0];   // stages 1,3,5 = set 0; 2,4,6 = set 1
-            bq.set(c[0], c[1], c[2], c[3], c[4]);
-        } else {
-            bq.set(0, 0, 128, 0, 0);                         // (128 x) >> 7 = x exactly
-        }
-    }
-    constexpr int kOutLane = 8;
-    const bool is_out = sec == kOutLane;
-    int yprev = 0;
-
-    Q15TileRegs pre;
-    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
-    for (int k = 0; k <= SA_NPTS / kTile; ++k) {   // one extra block drains the pipeline
-        const bool live = k < SA_NPTS / kTile;
-        if (live) q15_store_tile(pre, tin, lane, prm.win_mode);
+    for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
+        q15_stage_tile(in, rom, tin, f0, batch, n0, lane, prm.win_mode);
         __syncthreads();
-        // the next tile's HBM reads fly while this tile is being filtered
-        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
-        const int nsteps = live ? kTile / 8 : 1;
-        uint4 pk = make_uint4(0, 0, 0, 0);
-        if (live) pk = *reinterpret_cast<const uint4 *>(&tin[fr][0]);
-        for (int g = 0; g < nsteps; ++g) {
-            const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
-            if (live && g + 1 < nsteps) pk = *reinterpret_cast<const uint4 *>(&tin[fr][8 * (g + 1)]);   // one group ahead
-            int ys[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int xin = (e & 1) ? hi16(w[e >> 1]) : lo16(w[e >> 1]);
-                // lane 0 of the row has no left neighbour: bound_ctrl = false keeps `old` = xin there
-                const int x = __builtin_amdgcn_update_dpp(xin, yprev, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-                yprev = bq.step(x);
-                ys[e] = yprev;
-            }
-            // lane 8 holds samples T0 .. T0+7 with T0 = 256k + 8g - 8 (nothing valid before the first group)
-            const int T0 = k * kTile + 8 * g - kOutLane;
-            if (is_out && T0 >= 0)
-                *reinterpret_cast<uint4 *>(&ring[fr][T0 & (kRing - 1)]) =
-                    make_uint4(pack2(ys[0], ys[1]), pack2(ys[2], ys[3]), pack2(ys[4], ys[5]), pack2(ys[6], ys[7]));
-        }
+        q15_flush_tile<kRowPitch>(out, tin, 0, f0, batch, n0, lane);
         __syncthreads();
-        if (k >= 1) q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile) & (kRing - 1), f0, batch, (k - 1) * kTile, lane);
     }
-    SA_Q15_STAMP_END();
 }
 
 // ------------------------------------------------------------------------------------------ IIR, Q7, second form
@@ -364,9 +217,40 @@ __global__ __launch_bounds__(64) void filter_q15_kernel(const int16_t *__restric
 // 9 vector instructions per step, none depending on the one before it (q7_step); lanes: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample
 // T - 8 at step T: every group of 8 steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input
 // shift register.  Arithmetic identical to BiqQ7::step (new/filter_iir_cust.vhd:96-117).
-constexpr int kV2Waves = 4;                       // waves per workgroup
+#ifndef SA_Q15_WAVES
+#define SA_Q15_WAVES 4
+#endif
+constexpr int kV2Waves = SA_Q15_WAVES;            // waves per workgroup (one per SIMD of the CU; A/B builds: 8 = two per SIMD)
+// lane 8 of every row that carries a frame
+constexpr unsigned long long kOutMask = kFramesPerWave >= 4 ? 0x0100010001000100ull : kFramesPerWave == 2 ? 0x0000000001000100ull : 0x0100ull;
 constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
 constexpr int kInPitch = kInRing + 8;
+
+// window the loaded tile and put it into its half (col0 = 0 or kTile) of the wave's input ring: 16 bytes per lane
+__device__ __forceinline__ void q15_window_into_ring(const Q15TileRegs &r, int16_t (*dst)[kInPitch], int col0, int lane, int win_mode)
+{
+#pragma unroll
+    for (int i = 0; i < kTilePasses; ++i) {
+        const int row = kTileRows * i + lane / kTileLanes;
+        const int col = col0 + (lane % kTileLanes) * 8;
+        const unsigned xs[4] = {r.x[i].x, r.x[i].y, r.x[i].z, r.x[i].w};
+        const unsigned cs[4] = {r.c[i].x, r.c[i].y, r.c[i].z, r.c[i].w};
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int a, b;
+            if (win_mode == SA_WIN_RTL_SIGNED) {
+                a = win_rtl(lo16(xs[q]), lo16(cs[q]));
+                b = win_rtl(hi16(xs[q]), hi16(cs[q]));
+            } else {
+                a = win_u16(lo16(xs[q]), lo16(cs[q]));
+                b = win_u16(hi16(xs[q]), hi16(cs[q]));
+            }
+            o[q] = pack2(a, b);
+        }
+        if (tile_lane_on(lane)) *reinterpret_cast<uint4 *>(&dst[row][col]) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
 
 // One block = one time step, written in the cyclic order the issue logic likes best.  With x = the LEFT neighbour's
 // output (read in place by the DPP forms), y = the lane's own, and per step
@@ -652,6 +536,7 @@ __device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const i
         const int row = kTileRows * i + lane / kTileLanes;
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
+        if (!tile_lane_on(lane)) continue;
         const int sc = (src_col + col) & (kRing - 1);       // 8-sample chunks: the ring wraps between chunks only
         const int4 a = *reinterpret_cast<const int4 *>(&src[row][sc]);
         const int4 b = *reinterpret_cast<const int4 *>(&src[row][sc + 4]);
@@ -677,13 +562,16 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
     int (*ring)[kRingPitch] = ring_all[wave];
-    const int fr = lane >> 4;           // frame slot in this wave
+    const int fr = (lane >> 4) < kFramesPerWave ? (lane >> 4) : kFramesPerWave - 1;   // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
     if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
     SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
 
-    // taps, pre-shifted by 9 (see BiqQ7); identity = (128 x) >> 7
+#ifdef SA_AB_Q15_PRIO              // A/B builds only: the cascade's lone wave ahead of whatever shares its SIMD
+    __builtin_amdgcn_s_setprio(SA_AB_Q15_PRIO);
+#endif
+    // taps, pre-shifted by 9; identity = (128 x) >> 7
     int cB2 = 128 << 9, cB1 = 0, cB0 = 0, nA0 = 0, nA1 = 0;
     if (l16 >= 1 && l16 <= 6) {
         const int sec = l16 - 1;
@@ -695,7 +583,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     // are identity stages, s2 = 0) at the start of a group
     const int kin = (16 - l16) & 15;                       // 0..7 for the input lanes
     const bool is_in = kin < 8;
-    const unsigned long long out_mask = 0x0100010001000100ull;   // lane 8 of every row
+    const unsigned long long out_mask = kOutMask;                  // lane 8 of every row that carries a frame
     const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
     const uint16_t *xrow = reinterpret_cast<const uint16_t *>(&tin[fr][0]) + (is_in ? kin : 0);
     const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const uint16_t *)xrow;
@@ -723,31 +611,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     q15_load_tile(in, rom, f0, batch, 0, lane, pre);
     for (int k = 0; k <= SA_NPTS / kTile; ++k) {           // one extra block drains the pipeline
         const bool live = k < SA_NPTS / kTile;
-        if (live) {
-            // window the tile and put it into its half of the input ring
-            int16_t (*dst)[kInPitch] = tin;
-#pragma unroll
-            for (int i = 0; i < kTilePasses; ++i) {
-                const int row = kTileRows * i + lane / kTileLanes;
-                const int col = (k & 1) * kTile + (lane % kTileLanes) * 8;
-                const unsigned xs[4] = {pre.x[i].x, pre.x[i].y, pre.x[i].z, pre.x[i].w};
-                const unsigned cs[4] = {pre.c[i].x, pre.c[i].y, pre.c[i].z, pre.c[i].w};
-                unsigned o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int a, b;
-                    if (prm.win_mode == SA_WIN_RTL_SIGNED) {
-                        a = win_rtl(lo16(xs[q]), lo16(cs[q]));
-                        b = win_rtl(hi16(xs[q]), hi16(cs[q]));
-                    } else {
-                        a = win_u16(lo16(xs[q]), lo16(cs[q]));
-                        b = win_u16(hi16(xs[q]), hi16(cs[q]));
-                    }
-                    o[q] = pack2(a, b);
-                }
-                *reinterpret_cast<uint4 *>(&dst[row][col]) = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        }
+        if (live) q15_window_into_ring(pre, tin, (k & 1) * kTile, lane, prm.win_mode);
         wave_lds_sync();
         // the next tile's HBM reads fly while this tile is being filtered
         if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
@@ -760,6 +624,170 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         else group(k * kTile, xrow[i0]);
         wave_lds_sync();
         if (k >= 1) q7_flush_tile(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane);
+    }
+    SA_Q15_STAMP_END();
+}
+
+// ------------------------------------------------------------------------------------------ IIR, wide Q2.14 form
+// Mode 0xA2 (the build's own spec, oracle/specan_oracle.c:or_iir_sos_q14; the six sections scripts/fft_analyzer_gui.py:108-157
+// designs and :1186-1192 cuts down to two): per section, direct form I,
+//     y[n] = sat16( (b0 x[n] + b1 x[n-1] + b2 x[n-2] - a1 y[n-1] - a2 y[n-2] + 8192) >> 14 ),
+// int16 taps and samples.  The exact sum needs 34 bits.  It is kept in two 32-bit accumulators without a single 64-bit
+// instruction: every tap (and every negated feedback tap, -a in [-32767, 32768]) splits as c = 2^14 ch + cl with
+// cl in [-8192, 8191] and ch in {-2..2}, so
+//     acc_l = 8192 + sum cl v   (|acc_l| <= 5 * 2^13 * 2^15 + 2^13 < 2^31, no wrap at any partial sum)
+//     acc_h =        sum ch v   (|acc_h| <= 10 * 2^15)
+//     (acc + 8192) >> 14 = acc_h + (acc_l >> 14)            exactly (acc_h is an integer: the floor passes it)
+// and the two products a packed-int16 dot product forms per instruction halve the count: with the lane's last two outputs
+// and the neighbour's last two outputs held as packed pairs P = (lo: y[n-1], hi: y[n]), one step is
+//     acc  = dot2(P_own[n-1], (-a2, -a1), 8192 | 0)          v_dot2_i32_i16, low and high half: 2 instructions
+//     X    = P_neighbour[n-1]                                v_mov_b32_dpp row_ror:1 = (x[n-1], x[n])
+//     acc += dot2(X, (b1, b0));  acc += dot2(X_prev, (b2, 0))                                   4 instructions
+//     w    = acc_h + (acc_l >> 14)                           v_ashrrev_i32, v_add_u32
+//     P_own[n] = (sat16(w[n-1]), sat16(w[n]))                v_cvt_pk_i16_i32: saturation and packing in ONE instruction
+// = 10 vector instructions per step against 9 of the Q7 form (filter_q7_kernel<false>) and about 40 of the round-1 form
+// (five 64-bit multiply-adds, a 64-bit shift, two compares and selects, three cross-lane moves).  Everything else is
+// the Q7 kernel's structure: four waves per workgroup and one workgroup per CU at B = 4096 (one wave per SIMD in every
+// placement scenario, profiles/r2_q15_placement.txt), lanes 0 and 9..15 of the row an input shift register refilled by
+// one 16-bit LDS read per eight steps (identity sections: b0 = 16384 gives w = x exactly), lanes 7..8 delay stages so
+// that lane 8 emits sample T - 8 at step T, the tile loop ONE pinned asm statement.  The outputs leave as packed int16
+// (the pairs of the odd steps, v[52:55]: one 16-byte LDS store per eight steps), so the output ring is half the Q7 kernel's.
+struct W14Taps {
+    unsigned c01l, c01h, c2l, c2h, cfbl, cfbh;      // packed (lo, hi) int16 pairs: (b1, b0), (b2, 0), (-a2, -a1); low / high split
+};
+__device__ __forceinline__ void w14_split(int c, int &cl, int &ch)
+{
+    cl = ((c + 8192) & 16383) - 8192;
+    ch = (c - cl) >> 14;
+}
+__device__ __forceinline__ W14Taps w14_taps(int b0, int b1, int b2, int a1, int a2)
+{
+    int b0l, b0h, b1l, b1h, b2l, b2h, n1l, n1h, n2l, n2h;
+    w14_split(b0, b0l, b0h); w14_split(b1, b1l, b1h); w14_split(b2, b2l, b2h);
+    w14_split(-a1, n1l, n1h); w14_split(-a2, n2l, n2h);
+    W14Taps t;
+    t.c01l = pack2(b1l, b0l); t.c01h = pack2(b1h, b0h);
+    t.c2l = pack2(b2l, 0);    t.c2h = pack2(b2h, 0);
+    t.cfbl = pack2(n2l, n1l); t.cfbh = pack2(n2h, n1h);
+    return t;
+}
+
+// what one tile hands to the next: the eight pair registers of the group, the two unsaturated outputs and the two
+// neighbour pairs the next block reads
+struct W14Carry {
+    unsigned p[8];
+    int w0, w1;
+    unsigned x0, x1;
+};
+
+// block e of a group: PP = the pair of block e - 1, PC = this block's, (XC, XP) = the neighbour pair registers of this /
+// the previous block, (WC, WP) = the unsaturated outputs likewise.  SEL: the refill select of the group's first block.
+#define SA_W14_BLOCK(PP, PC, XC, XP, WC, WP, SEL)                                                                      \
+    "v_dot2_i32_i16 %[al], " PP ", %[cfbl], %[k]\n\t"                                                                  \
+    "v_dot2_i32_i16 %[ah], " PP ", %[cfbh], 0\n\t"                                                                     \
+    "v_mov_b32_dpp " XC ", " PP " row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                                            \
+    "v_dot2_i32_i16 %[al], " XC ", %[c01l], %[al]\n\t"                                                                 \
+    "v_dot2_i32_i16 %[ah], " XC ", %[c01h], %[ah]\n\t"                                                                 \
+    "v_dot2_i32_i16 %[al], " XP ", %[c2l], %[al]\n\t"                                                                  \
+    "v_dot2_i32_i16 %[ah], " XP ", %[c2h], %[ah]\n\t"                                                                  \
+    "v_ashrrev_i32 %[al], 14, %[al]\n\t"                                                                               \
+    "v_add_u32 " WC ", %[ah], %[al]\n\t" SEL                                                                           \
+    "v_cvt_pk_i16_i32 " PC ", " WP ", " WC "\n\t"
+// pair registers: odd blocks v52..v55 (what lane 8 stores), even blocks v56..v59
+#define SA_W14_GROUP(RD_OFF, WR_OFF)                                                                                   \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                         \
+    SA_W14_BLOCK("v55", "v56", "%[x0]", "%[x1]", "%[w0]", "%[w1]", "v_cndmask_b32_e64 %[w0], %[w0], %[xin], %[inm]\n\t") \
+    "ds_read_i16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
+    SA_W14_BLOCK("v56", "v52", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
+    SA_W14_BLOCK("v52", "v57", "%[x0]", "%[x1]", "%[w0]", "%[w1]", "")                                                 \
+    SA_W14_BLOCK("v57", "v53", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
+    SA_W14_BLOCK("v53", "v58", "%[x0]", "%[x1]", "%[w0]", "%[w1]", "")                                                 \
+    SA_W14_BLOCK("v58", "v54", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
+    SA_W14_BLOCK("v54", "v59", "%[x0]", "%[x1]", "%[w0]", "%[w1]", "")                                                 \
+    SA_W14_BLOCK("v59", "v55", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
+    "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF "\n\t"                                                              \
+    "s_mov_b64 exec, %[sv]\n\t"
+
+// `iters` x 4 groups x 8 steps.  xa: LDS byte address of the lane's refill slot of the first group; ra: of the ring slot
+// of its outputs.  The refill is requested one group ahead (lgkmcnt(1): everything but the store behind it).
+__device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned xa, unsigned ra, unsigned long long in_mask,
+                                         unsigned long long out_mask, int iters)
+{
+    int xin, al, ah;
+    unsigned long long saved;
+    asm volatile(
+        "v_mov_b32 v56, %[p0]\n\tv_mov_b32 v52, %[p1]\n\tv_mov_b32 v57, %[p2]\n\tv_mov_b32 v53, %[p3]\n\t"
+        "v_mov_b32 v58, %[p4]\n\tv_mov_b32 v54, %[p5]\n\tv_mov_b32 v59, %[p6]\n\tv_mov_b32 v55, %[p7]\n\t"
+        "ds_read_i16 %[xin], %[xa]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        ".p2align 6\n"
+        "1:\n\t"
+        SA_W14_GROUP("16", "0") SA_W14_GROUP("32", "16") SA_W14_GROUP("48", "32") SA_W14_GROUP("64", "48")
+        "v_add_u32 %[xa], 64, %[xa]\n\t"
+        "v_add_u32 %[ra], 64, %[ra]\n\t"
+        "s_add_i32 %[cnt], %[cnt], -1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mov_b32 %[p0], v56\n\tv_mov_b32 %[p1], v52\n\tv_mov_b32 %[p2], v57\n\tv_mov_b32 %[p3], v53\n\t"
+        "v_mov_b32 %[p4], v58\n\tv_mov_b32 %[p5], v54\n\tv_mov_b32 %[p6], v59\n\tv_mov_b32 %[p7], v55"
+        : [p0] "+v"(c.p[0]), [p1] "+v"(c.p[1]), [p2] "+v"(c.p[2]), [p3] "+v"(c.p[3]), [p4] "+v"(c.p[4]), [p5] "+v"(c.p[5]),
+          [p6] "+v"(c.p[6]), [p7] "+v"(c.p[7]), [w0] "+v"(c.w0), [w1] "+v"(c.w1), [x0] "+v"(c.x0), [x1] "+v"(c.x1),
+          [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [al] "=&v"(al), [ah] "=&v"(ah), [cnt] "+s"(iters), [sv] "=&s"(saved)
+        : [c01l] "v"(t.c01l), [c01h] "v"(t.c01h), [c2l] "v"(t.c2l), [c2h] "v"(t.c2h), [cfbl] "v"(t.cfbl), [cfbh] "v"(t.cfbh),
+          [k] "s"(8192), [inm] "s"(in_mask), [outm] "s"(out_mask)
+        : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+}
+
+__global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                                    int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tin_all[kV2Waves][kFramesPerWave][kInPitch];
+    __shared__ __attribute__((aligned(16))) int16_t ring_all[kV2Waves][kFramesPerWave][kRingPitch];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int16_t (*tin)[kInPitch] = tin_all[wave];
+    int16_t (*ring)[kRingPitch] = ring_all[wave];
+    const int fr = (lane >> 4) < kFramesPerWave ? (lane >> 4) : kFramesPerWave - 1;   // frame slot in this wave
+    const int l16 = lane & 15;          // role inside the row: 0 = input, 1..6 = sections 0..5, 7..8 = delay, 9..15 = input
+    const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
+    if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
+    SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
+
+#ifdef SA_AB_Q15_PRIO              // A/B builds only: the cascade's lone wave ahead of whatever shares its SIMD
+    __builtin_amdgcn_s_setprio(SA_AB_Q15_PRIO);
+#endif
+    W14Taps taps = w14_taps(16384, 0, 0, 0, 0);              // identity: (16384 x + 8192) >> 14 = x exactly
+    if (l16 >= 1 && l16 <= prm.nsec_wide) {
+        const int16_t *c = &prm.sos_q14[(l16 - 1) * 6];      // scipy row order [b0, b1, b2, a0, a1, a2], a0 ignored (= 1.0)
+        taps = w14_taps(c[0], c[1], c[2], c[4], c[5]);
+    }
+    const int kin = (16 - l16) & 15;                         // 0..7 for the input lanes: lanes 0, 15, .., 9 take samples T0 .. T0+7
+    const bool is_in = kin < 8;
+    const unsigned long long out_mask = kOutMask;                  // lane 8 of every row that carries a frame
+    const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
+    const int16_t *xrow = &tin[fr][0] + (is_in ? kin : 0);
+    const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int16_t *)xrow;
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)(&ring[fr][0]);
+
+    W14Carry c = {};
+    Q15TileRegs pre;
+    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
+    for (int k = 0; k <= SA_NPTS / kTile; ++k) {           // one extra pass drains the pipeline
+        const bool live = k < SA_NPTS / kTile;
+        if (live) q15_window_into_ring(pre, tin, (k & 1) * kTile, lane, prm.win_mode);
+        wave_lds_sync();
+        // the next tile's HBM reads fly while this tile is being filtered
+        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
+        // Sample m lives in ring slot (m + 8) mod kRing (lane 8 holds samples T0 - 8 .. T0 - 1 at the end of the group that
+        // starts at step T0).  The drain pass runs one iteration = four groups: the first delivers the frame's last eight
+        // samples, the other three filter whatever the input ring holds into slots that were flushed long ago.
+        const int i0 = (k & 1) * kTile;
+        w14_tile(c, taps, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, live ? kTile / 32 : 1);
+        wave_lds_sync();
+        if (k >= 1)
+            q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile + 8) & (kRing - 1), f0, batch, (k - 1) * kTile, lane, kRing - 1);
     }
     SA_Q15_STAMP_END();
 }
@@ -1002,25 +1030,21 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
 
 #ifdef SA_Q15_SECOND_TU
 hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                     const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
+                                     const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
 #else
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
+                                const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
 #endif
 {
     if (batch <= 0) return hipSuccess;
-    const dim3 grid((batch + kFramesPerWave - 1) / kFramesPerWave), block(64);
-#ifdef SA_Q7_OLD                       // A/B builds only (tools/ab_libs.py takes two libraries): the round-1 cascade
-    const bool old_form = true;
-#else
-    const bool old_form = false;
-#endif
-    if (p.filter == SA_FILTER_WIDE) {
-        hipExtLaunchKernelGGL(filter_q15_kernel<true>, grid, block, 0, stream, nullptr, stop, 0, in, out_time, batch, p, t.rom);
-    } else if (p.filter == SA_FILTER_NONE || old_form) {
-        hipExtLaunchKernelGGL(filter_q15_kernel<false>, grid, block, 0, stream, nullptr, stop, 0, in, out_time, batch, p, t.rom);
+    const int per_wg = kFramesPerWave * kV2Waves;
+    const dim3 grid_wg((batch + per_wg - 1) / per_wg), block_wg(64 * kV2Waves);
+    if (p.filter == SA_FILTER_NONE) {
+        hipExtLaunchKernelGGL(window_q15_kernel, dim3((batch + kFramesPerWave - 1) / kFramesPerWave), dim3(64), 0, stream, ev.start,
+                              ev.stop, 0, in, out_time, batch, p, t.rom);
+    } else if (p.filter == SA_FILTER_WIDE) {
+        hipExtLaunchKernelGGL(filter_w14_kernel, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
     } else {
-        const int per_wg = kFramesPerWave * kV2Waves;
         // B1 = 0 in both coefficient sets (wire order b0,b1,b2,a0,a1,a2 per set): the seven-instruction step
         const bool nob1 = p.c12[1] == 0 && p.c12[7] == 0;
 #ifdef SA_AB_Q7_NO_ELISION            // A/B builds only
@@ -1029,18 +1053,16 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
         const bool use_nb1 = nob1;
 #endif
         if (use_nb1)
-            hipExtLaunchKernelGGL(filter_q7_kernel<true>, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr,
-                                  stop, 0, in, out_time, batch, p, t.rom);
+            hipExtLaunchKernelGGL(filter_q7_kernel<true>, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
         else
-            hipExtLaunchKernelGGL(filter_q7_kernel<false>, dim3((batch + per_wg - 1) / per_wg), dim3(64 * kV2Waves), 0, stream, nullptr,
-                                  stop, 0, in, out_time, batch, p, t.rom);
+            hipExtLaunchKernelGGL(filter_q7_kernel<false>, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
     }
     return hipGetLastError();
 }
 
 #ifndef SA_Q15_SECOND_TU
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
-                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop)
+                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
 {
     if (batch <= 0) return hipSuccess;
     const dim3 grid(batch), block(kFftWide);
@@ -1048,7 +1070,7 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     auto k = apply_window ? fft_q15_kernel<true> : fft_q15_kernel<false>;
     const hipError_t e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
     if (e != hipSuccess) return e;
-    hipExtLaunchKernelGGL(k, grid, block, lds, stream, nullptr, stop, 0, in_time, out_iq, batch, p, t.rom, t.tw);
+    hipExtLaunchKernelGGL(k, grid, block, lds, stream, ev.start, ev.stop, 0, in_time, out_iq, batch, p, t.rom, t.tw);
     return hipGetLastError();
 }
 #endif

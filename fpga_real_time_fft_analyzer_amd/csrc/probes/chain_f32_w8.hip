@@ -622,7 +622,7 @@ hipError_t set_lds8(K kernel)
 
 template <int NSEC, bool UNIT>
 hipError_t launch8(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb, const SaIirK8 &ka,
-                   hipStream_t stream, hipEvent_t stop)
+                   hipStream_t stream, SaLaunchEv ev)
 {
     const dim3 grid(batch), block(kT8);
     hipError_t e = hipSuccess;
@@ -632,7 +632,7 @@ hipError_t launch8(const float *in, void *out, int batch, int out_kind, const Sa
                               : chain_f32_w8_kernel<NSEC, UNIT, OUTK, false>;                          \
         e = set_lds8(kern);                                                                            \
         if (e != hipSuccess) return e;                                                                 \
-        hipExtLaunchKernelGGL(kern, grid, block, kLds8, stream, nullptr, stop, 0, in, out, batch, tb.twT8, tb.twB, tb.twC, \
+        hipExtLaunchKernelGGL(kern, grid, block, kLds8, stream, ev.start, ev.stop, 0, in, out, batch, tb.twT8, tb.twB, tb.twC, \
                               tb.lanetab8, ka);                                                        \
     } while (0)
     switch (out_kind) {
@@ -648,19 +648,19 @@ hipError_t launch8(const float *in, void *out, int batch, int out_kind, const Sa
 }  // namespace
 
 hipError_t sa_launch_chain_f32_w8(const float *in, void *out, int batch, int out_kind, const SaF32Tables &tb,
-                                  hipStream_t stream, hipEvent_t stop)
+                                  hipStream_t stream, SaLaunchEv ev)
 {
     if (batch <= 0) return hipSuccess;
     if (!tb.iir8 || tb.iir8->nsec <= 0 || out_kind == SA_OUT_TIME) return hipErrorNotSupported;
     const SaIirK8 &ka = *tb.iir8;
     const bool unit = ka.unit != 0;
     switch (ka.nsec) {
-        case 2: return unit ? launch8<2, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch8<2, false>(in, out, batch, out_kind, tb, ka, stream, stop);
-        case 4: return unit ? launch8<4, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch8<4, false>(in, out, batch, out_kind, tb, ka, stream, stop);
-        case 6: return unit ? launch8<6, true>(in, out, batch, out_kind, tb, ka, stream, stop)
-                            : launch8<6, false>(in, out, batch, out_kind, tb, ka, stream, stop);
+        case 2: return unit ? launch8<2, true>(in, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch8<2, false>(in, out, batch, out_kind, tb, ka, stream, ev);
+        case 4: return unit ? launch8<4, true>(in, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch8<4, false>(in, out, batch, out_kind, tb, ka, stream, ev);
+        case 6: return unit ? launch8<6, true>(in, out, batch, out_kind, tb, ka, stream, ev)
+                            : launch8<6, false>(in, out, batch, out_kind, tb, ka, stream, ev);
         default: return hipErrorNotSupported;
     }
 }

@@ -155,17 +155,22 @@ struct SaF32Tables {
     const SaIirK8 *iir8;           // HOST pointer (null = no IIR)
 };
 
-// `stop` (may be null): an event bound to the completion of the call's LAST kernel (hipExtLaunchKernel attaches it to
-// the dispatch packet itself: no marker packet between two launches, unlike hipEventRecord after the launch).
+// Events of a launch (either may be null), attached to the dispatch packet itself by hipExtLaunchKernel: no marker
+// packet between two launches, unlike hipEventRecord around the launch.  `stop` is bound to the completion of the
+// call's LAST kernel (ordering of uploads, joins of overlapped launches); `start` to the begin of its FIRST kernel
+// (only while sa_set_profiling is on: device time of a call = stop - start).
+struct SaLaunchEv {
+    hipEvent_t start, stop;
+};
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
-                               hipStream_t stream, hipEvent_t stop);
+                               hipStream_t stream, SaLaunchEv ev);
 // the same chain on int16 samples (chain_f32_i16.hip): x = float(sample) * in_scale, then exactly the float32 path
 hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &t,
-                                   hipStream_t stream, hipEvent_t stop);
+                                   hipStream_t stream, SaLaunchEv ev);
 // the 512-thread form (chain_f32_w8.hip): IIR modes with the three spectrum outputs; returns hipErrorNotSupported
 // for anything else (the caller then takes sa_launch_chain_f32)
 hipError_t sa_launch_chain_f32_w8(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
-                                  hipStream_t stream, hipEvent_t stop);
+                                  hipStream_t stream, SaLaunchEv ev);
 
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM
@@ -173,9 +178,9 @@ struct SaQ15Tables {
 };
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
+                                const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);
 // the same cascade with 128-sample tiles (chain_q15_t128.hip): for launches that overlap (half the LDS per workgroup)
 hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                     const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
+                                     const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
-                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, hipEvent_t stop);
+                             const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);

@@ -367,15 +367,25 @@ struct sa_handle {
     // gpurun_out/ab_ov.log).  Uploads, stream switches and sa_destroy wait for that event; the caller's stream is
     // never touched after the call that passed it has returned, so the caller may destroy it at any time (touching
     // a destroyed stream crashes inside the runtime: gpurun_out/gpu_tests_b.log).  `last_stream` is compared, never
-    // dereferenced -- except for the capture query of control_allowed(), on a stream whose capture is open.
+    // dereferenced; the capture query of control_allowed() touches `capture_stream` only, a stream whose capture the
+    // handle has not yet seen closed (the caller ends a capture before destroying its stream: include/specan.h).
     hipStream_t ctl = nullptr;
     hipEvent_t launched = nullptr, uploaded = nullptr;
     bool launched_valid = false;           // `launched` has been bound to a launch at least once
     unsigned upload_gen = 0;               // number of uploads issued so far
     unsigned seen_gen = 0;                 // ordered mode: uploads the data stream has waited for
-    hipStream_t last_stream = nullptr;     // stream of the most recent ordered-mode process call
+    hipStream_t last_stream = nullptr;     // stream of the most recent ordered-mode process call (compared, never used)
     bool have_last_stream = false;
-    bool last_call_captured = false;       // that call was captured into a graph (see control_allowed)
+    // a process call was captured into a graph on `capture_stream` and that capture has not been seen closed yet
+    // (control_allowed): sticky across calls on OTHER streams; cleared by the query on that stream reporting "none"
+    bool capture_open = false;
+    hipStream_t capture_stream = nullptr;
+    // ---- launch timing (opt-in, sa_set_profiling): a ring of timing-enabled event pairs; ordered-mode call k binds
+    // pair k mod n to the begin of its first and the end of its last kernel (hipExtLaunchKernel: the events ride on the
+    // dispatch packets, no marker packets), and `launched` aliases the pair's stop event meanwhile
+    std::vector<hipEvent_t> prof_start, prof_stop;
+    hipEvent_t launched_own = nullptr;     // the handle's own (timing-disabled) completion event
+    unsigned long long prof_calls = 0;
     // ---- overlapped launches (opt-in, sa_set_overlap): consecutive process calls alternate over `overlap` internal
     // streams so that the tail of one launch runs under the head of the next; see include/specan.h
     int overlap = 1;
@@ -489,21 +499,23 @@ constexpr size_t kStageBytes = sizeof(SaIirLaneTab8) > sizeof(SaIirLaneTab) ? si
 static_assert(kStageBytes >= sizeof(float) * SA_NPTS, "a staging slot holds any table of the handle");
 
 // Control-plane calls change host state and device tables; a process call that is being captured into a hipGraph
-// has frozen the host part (kernel arguments) but not the tables, so such calls are refused while the capture of the
-// handle's most recent process call is still open.  Checked at the top of every control-plane entry point, before
-// anything is changed.  (The query touches the stream of a captured call only: that stream is alive while its
-// capture is open, and an error from the query -- capture ended, stream gone -- reads as "not capturing".)
+// has frozen the host part (kernel arguments) but not the tables, so such calls are refused while a capture that took
+// one of the handle's process calls is still open.  Checked at the top of every control-plane entry point, before
+// anything is changed.  The record is sticky: a later, uncaptured call on ANOTHER stream does not clear it; only the
+// query on the capturing stream does (here, or in begin_call when that stream is used again), and once it has reported
+// "none" that stream is never queried again on the record's behalf.
 int control_allowed(sa_handle *h)
 {
-    if (!h->last_call_captured) return SA_OK;
+    if (!h->capture_open) return SA_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->last_stream, &cs) != hipSuccess) {
+    if (hipStreamIsCapturing(h->capture_stream, &cs) != hipSuccess) {
         (void)hipGetLastError();
         cs = hipStreamCaptureStatusNone;
     }
     if (cs != hipStreamCaptureStatusNone)
-        return fail(h, SA_ESTATE, "control-plane call while the handle's stream is being captured into a graph");
-    h->last_call_captured = false;
+        return fail(h, SA_ESTATE, "control-plane call while a stream that captured one of the handle's calls is still capturing");
+    h->capture_open = false;
+    h->capture_stream = nullptr;
     return SA_OK;
 }
 
@@ -536,6 +548,7 @@ int upload(sa_handle *h, void *dst, const void *src, size_t bytes)
 //     what the caller enqueued before call k, not on kernels k-1 .. k-d+1, and may run beside them.
 struct CallCtx {
     hipStream_t stream;
+    hipEvent_t start;         // bound to the call's first kernel while sa_set_profiling is on, else null
     hipEvent_t stop;          // bound to the call's last kernel by the launcher (null inside a stream capture)
     int slot;
     bool overlapped, captured;
@@ -574,11 +587,19 @@ int fit_overlap_streams(sa_handle *h, hipStream_t user)
 int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
 {
     c->stream = user;
+    c->start = nullptr;
     c->slot = 0;
     c->overlapped = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     SA_HIP(h, hipStreamIsCapturing(user, &cs));
     c->captured = cs != hipStreamCaptureStatusNone;
+    if (c->captured) {
+        h->capture_open = true;
+        h->capture_stream = user;
+    } else if (h->capture_open && h->capture_stream == user) {
+        h->capture_open = false;             // that stream's capture has ended
+        h->capture_stream = nullptr;
+    }
     if (h->overlap > 1) {
         if (c->captured)
             return fail(h, SA_ESTATE, "overlapped launches (sa_set_overlap > 1) cannot be captured into a graph");
@@ -616,7 +637,11 @@ int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
     }
     h->last_stream = user;
     h->have_last_stream = true;
-    h->last_call_captured = c->captured;
+    if (!c->captured && !h->prof_stop.empty()) {          // timed call: the ring's next pair; `launched` follows it
+        const size_t i = (size_t)(h->prof_calls % h->prof_stop.size());
+        c->start = h->prof_start[i];
+        h->launched = h->prof_stop[i];
+    }
     // a captured record would tie the event to the graph; replays are ordered by the caller (include/specan.h)
     c->stop = c->captured ? nullptr : h->launched;
 #ifdef SA_AB_NO_STOP_EVENT               // A/B builds only: prices the stop event of the ordered mode
@@ -633,7 +658,10 @@ int end_call(sa_handle *h, const CallCtx &c)
         ++h->ov_calls;
         return SA_OK;
     }
-    if (!c.captured) h->launched_valid = true;
+    if (!c.captured) {
+        h->launched_valid = true;
+        if (!h->prof_stop.empty()) ++h->prof_calls;
+    }
     return SA_OK;
 }
 
@@ -845,7 +873,8 @@ int sa_create(int device, sa_handle **out)
     } while (0)
     SA_HIPC(hipSetDevice(device));
     SA_HIPC(hipStreamCreateWithFlags(&h->ctl, hipStreamNonBlocking));
-    SA_HIPC(hipEventCreateWithFlags(&h->launched, hipEventDisableTiming));
+    SA_HIPC(hipEventCreateWithFlags(&h->launched_own, hipEventDisableTiming));
+    h->launched = h->launched_own;
     SA_HIPC(hipEventCreateWithFlags(&h->uploaded, hipEventDisableTiming));
     for (int i = 0; i < sa_handle::kStage; ++i) {
         SA_HIPC(hipHostMalloc(&h->stage[i], kStageBytes, hipHostMallocDefault));
@@ -1002,7 +1031,9 @@ int sa_destroy(sa_handle *h)
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
-    if (h->launched) (void)hipEventDestroy(h->launched);
+    for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
+    if (h->launched_own) (void)hipEventDestroy(h->launched_own);
     if (h->uploaded) (void)hipEventDestroy(h->uploaded);
     if (h->ctl) (void)hipStreamDestroy(h->ctl);
     (void)hipFree(h->d_win_b);
@@ -1041,6 +1072,8 @@ int sa_set_overlap(sa_handle *h, int depth)
     if (depth < 1 || depth > sa_handle::kMaxOverlap) return fail(h, SA_EINVAL, "sa_set_overlap: depth must be 1..4");
     { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
     if (depth == h->overlap) return SA_OK;
+    if (depth > 1 && !h->prof_stop.empty())
+        return fail(h, SA_ESTATE, "sa_set_overlap: launch timing (sa_set_profiling) is for stream-ordered launches; turn it off first");
     SA_HIP(h, hipSetDevice(h->device));
     // leave the old mode with nothing of the handle's in flight (host wait on the handle's own work only)
     if (h->launched_valid) SA_HIP(h, hipEventSynchronize(h->launched));
@@ -1089,6 +1122,54 @@ int sa_debug_overlap_streams(sa_handle *h, void *stream, int *side_by_side)
             if (r == 0) *side_by_side = 0;
         }
     return SA_OK;
+}
+
+int sa_set_profiling(sa_handle *h, int ring)
+{
+    if (!h) return SA_EINVAL;
+    if (ring < 0 || ring > 65536) return fail(h, SA_EINVAL, "sa_set_profiling: ring must be 0..65536");
+    { const int rc = control_allowed(h); if (rc != SA_OK) return rc; }
+    if (ring > 0 && h->overlap > 1)
+        return fail(h, SA_ESTATE, "sa_set_profiling: launch timing is for stream-ordered launches (sa_set_overlap(h, 1) first)");
+    SA_HIP(h, hipSetDevice(h->device));
+    // nothing of the handle's in flight while the completion event changes hands
+    if (h->launched_valid) SA_HIP(h, hipEventSynchronize(h->launched));
+    h->launched_valid = false;
+    h->launched = h->launched_own;
+    for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
+    h->prof_start.clear();
+    h->prof_stop.clear();
+    h->prof_calls = 0;
+    for (int i = 0; i < ring; ++i) {
+        hipEvent_t a = nullptr, b = nullptr;
+        hipError_t e = hipEventCreate(&a);
+        if (e == hipSuccess) e = hipEventCreate(&b);
+        if (e != hipSuccess) {
+            if (a) (void)hipEventDestroy(a);
+            return fail(h, SA_EHIP, "sa_set_profiling: hipEventCreate", e);
+        }
+        h->prof_start.push_back(a);
+        h->prof_stop.push_back(b);
+    }
+    return SA_OK;
+}
+
+int sa_profile_read(sa_handle *h, float *ms, int cap)
+{
+    if (!h) return SA_EINVAL;
+    if (cap < 0 || (cap > 0 && !ms)) return fail(h, SA_EINVAL, "sa_profile_read: bad buffer");
+    if (h->prof_stop.empty()) return fail(h, SA_ESTATE, "sa_profile_read: sa_set_profiling is off");
+    SA_HIP(h, hipSetDevice(h->device));
+    const unsigned long long n = h->prof_stop.size();
+    unsigned long long have = h->prof_calls < n ? h->prof_calls : n;
+    if (have > (unsigned long long)cap) have = (unsigned long long)cap;
+    for (unsigned long long j = 0; j < have; ++j) {
+        const size_t i = (size_t)((h->prof_calls - have + j) % n);
+        SA_HIP(h, hipEventSynchronize(h->prof_stop[i]));
+        SA_HIP(h, hipEventElapsedTime(&ms[j], h->prof_start[i], h->prof_stop[i]));
+    }
+    return (int)have;
 }
 
 int sa_flush(sa_handle *h, void *stream)
@@ -1299,7 +1380,7 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
     SaQ15Params p;
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
-    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream, c.stop));
+    SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream, {c.start, c.stop}));
     return end_call(h, c);
 }
 
@@ -1316,7 +1397,7 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     q15_params(h, &p);
     const SaQ15Tables t = {h->d_rom, h->d_twq};
     if (p.filter == SA_FILTER_NONE) {
-        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream, c.stop));
+        SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream, {c.start, c.stop}));
         return end_call(h, c);
     }
     { const int rc = ensure_work(h, c.slot, batch, c.captured); if (rc != SA_OK) return rc; }
@@ -1329,9 +1410,9 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     const bool small_tiles = c.overlapped && h->overlap == 2;
 #endif
     SA_HIP(h, small_tiles
-                  ? sa_launch_filter_q15_t128(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr)
-                  : sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, nullptr));
-    SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream, c.stop));
+                  ? sa_launch_filter_q15_t128(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr})
+                  : sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr}));
+    SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream, {nullptr, c.stop}));
     return end_call(h, c);
 }
 
@@ -1366,9 +1447,9 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     } else if (h->filter_mode == SA_FILTER_CUSTOM) {
         t.iir8 = &h->plan8_custom;
     }
-    le = sa_launch_chain_f32_w8(in, out, batch, out_kind, t, c.stream, c.stop);
+    le = sa_launch_chain_f32_w8(in, out, batch, out_kind, t, c.stream, {c.start, c.stop});
 #endif
-    if (le == hipErrorNotSupported) le = sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, c.stop);
+    if (le == hipErrorNotSupported) le = sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, {c.start, c.stop});
     SA_HIP(h, le);
     return end_call(h, c);
 }
@@ -1395,7 +1476,7 @@ int sa_process_f32_i16(sa_handle *h, const int16_t *in, float scale, void *out, 
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
     }
-    SA_HIP(h, sa_launch_chain_f32_i16(in, scale, out, batch, out_kind, t, c.stream, c.stop));
+    SA_HIP(h, sa_launch_chain_f32_i16(in, scale, out, batch, out_kind, t, c.stream, {c.start, c.stop}));
     return end_call(h, c);
 }
 

@@ -37,7 +37,9 @@
  *   - hipGraph capture: process calls are capturable in ordered mode once sa_reserve() has sized
  *     the workspace.  A captured call freezes the control state of capture time in its kernel
  *     arguments; control-plane calls are refused (SA_ESTATE, nothing changed) while that capture
- *     is open, and after any control-plane call graphs captured earlier must be captured again.
+ *     is open -- also when other, uncaptured calls have been made on other streams meanwhile -- and
+ *     after any control-plane call graphs captured earlier must be captured again.  End a capture
+ *     before destroying the capturing stream (the handle asks that stream whether it still captures).
  *     Work replayed from a graph is not tracked by the handle: order it yourself (e.g. synchronise
  *     the replay stream) before a control-plane call.
  *   - frame length is fixed: SA_N = 16384 samples (gui.py:43-44, imp/dsp_system_top.vhd:440,
@@ -55,7 +57,7 @@ extern "C" {
 
 #define SA_N 16384
 #define SA_FRAME_BYTES 65536          /* gui.py:42  FRAME_SIZE_BYTES */
-#define SA_ABI_VERSION 3
+#define SA_ABI_VERSION 4
 
 /* error codes */
 #define SA_OK       0
@@ -105,8 +107,9 @@ const char *sa_last_error(const sa_handle *h);   /* h may be NULL: last sa_creat
  * capturable into a hipGraph then). */
 int sa_reserve(sa_handle *h, int max_batch);
 
-/* Overlapped launches (opt-in; build extension).  Frames are independent -- the reference resets
- * the filter state per frame (new/filter_iir12_cust.vhd:48-63) -- so consecutive batches need not
+/* Overlapped launches (opt-in; build extension).  Frames are independent -- every frame starts from a zero
+ * filter state: the RTL clears the biquad history whenever i_valid = '0' (new/filter_iir_cust.vhd:142-146,
+ * SURVEY quirk Q5), which this build applies once per frame -- so consecutive batches need not
  * run one after the other.  With depth d > 1, process call k runs on an internal stream of the
  * handle (k mod d), ordered after everything the caller's stream held when the call was made but
  * NOT after calls k-1 .. k-d+1: the tail of one launch runs under the head of the next (on the
@@ -131,6 +134,19 @@ int sa_get_overlap(const sa_handle *h, int *depth);
 int sa_debug_overlap_streams(sa_handle *h, void *stream, int *side_by_side);
 /* Make `stream` wait for every outstanding overlapped call of the handle (no host wait). */
 int sa_flush(sa_handle *h, void *stream);
+
+/* Launch timing (opt-in; measurement aid, no counterpart in the reference).  With ring = n > 0 every stream-ordered
+ * process call binds a pair of timing events to the BEGIN of its first kernel and the END of its last one -- the
+ * events ride on the dispatch packets themselves (hipExtLaunchKernel), nothing is put between two launches, so a train
+ * of calls runs as it does untimed -- and the handle keeps the pairs of the last n calls.  sa_profile_read() waits on
+ * the host for those calls and writes their device times in milliseconds, oldest first, into ms[0 .. return value)
+ * (at most cap).  A call with one kernel (the float chain, the bypassed integer chain) reports that kernel's duration;
+ * the integer chain with a cascade reports cascade + FFT including the gap between them.  Captured calls are not
+ * timed.  ring = 0 turns it off.  Refused (SA_ESTATE) while sa_set_overlap is above 1, and sa_set_overlap(d > 1) is
+ * refused while it is on: kernels that run beside each other have no per-call time.  Changing the ring waits on the
+ * host for the handle's own outstanding work. */
+int sa_set_profiling(sa_handle *h, int ring /* 0..65536 */);
+int sa_profile_read(sa_handle *h, float *ms, int cap);
 
 /* ---- control plane of the path (what the UART bytes do) -------------------------------- */
 /* new/command_control.vhd:53-58: accepts SA_FILTER_DEFAULT / CUSTOM / NONE (and SA_FILTER_WIDE). */

@@ -23,7 +23,7 @@ def test_header_declares_the_boundary():
 def test_library_exports_every_declared_symbol(hip_lib_built):
     for name in declared_symbols():
         assert hasattr(hip_lib_built, name), f"{name} declared in include/specan.h but not exported"
-    assert hip_lib_built.sa_abi_version() == 3
+    assert hip_lib_built.sa_abi_version() == 4
 
 
 def test_no_torch_or_oracle_linkage(hip_lib_built):

@@ -152,6 +152,7 @@ def test_overlapped_launches_q15(ch, torch_mod, oracle):
     sizes = [3, 17, 5, 64, 33, 2]
     xs = [rng.integers(-2048, 2048, (b, N)).astype(np.int16) for b in sizes]
     gui = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
+    wide = load_golden("g4_q15_frames.npz")["sos_q14"]
     ch.set_filter_mode(0x00)
     ch.set_overlap(2)
     s = torch.cuda.Stream()
@@ -162,13 +163,18 @@ def test_overlapped_launches_q15(ch, torch_mod, oracle):
             if k == 3:                                       # control plane between overlapped calls: custom coefficients
                 ch.load_coeffs_q7(gui)
                 ch.set_filter_mode(0xA1)
+            if k == 5:                                       # ... and the wide cascade (its 128-sample-tile build)
+                ch.load_sos_q14(wide)
+                ch.set_filter_mode(0xA2)
             outs.append(ch.process_q15(x))
         ch.flush()
         got = [o.cpu().numpy() for o in outs]
     s.synchronize()
     for k, x in enumerate(xs):
-        ref = oracle.chain_q15(x, None, 0, 0x00 if k < 3 else 0xA1, None if k < 3 else gui, None)
+        cmd = 0x00 if k < 3 else (0xA1 if k < 5 else 0xA2)
+        ref = oracle.chain_q15(x, None, 0, cmd, gui if cmd == 0xA1 else None, wide if cmd == 0xA2 else None)
         assert np.array_equal(got[k], ref), k
+    ch.set_filter_mode(0xA1)
     ch.set_overlap(1)
     assert np.array_equal(ch.process_q15(_dev(torch, xs[3])).cpu().numpy(), got[3])
 
@@ -328,22 +334,31 @@ GUI_UPLOAD = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
 
 
 @pytest.mark.parametrize("full_scale", [False, True], ids=["12bit", "fullscale"])
-@pytest.mark.parametrize("coeffs", ["default", "gui"])
+@pytest.mark.parametrize("coeffs", ["default", "gui", "wide"])
 def test_config4_whole_batch(ch, torch_mod, oracle, full_scale, coeffs):
     """BASELINE config 4 as SURVEY 8(d) defines it: B = 4096, int16 uniform in [-2048, 2047] (seed 2) and a
     second run uniform over the full int16 range, coefficient set (a) the fixed ALPHA/BETA cascade
     (imp/filter_pkg.vhd:54-68, mode 0x00) and (b) the GUI's default upload (gui.py:1186-1192, mode 0xA1);
     the window + cascade output AND the IQ frame of EVERY one of the 4096 frames equal the SA integer model
-    (oracle/specan_oracle.c; parity unpinned vs the RTL / xfft_0)."""
+    (oracle/specan_oracle.c; parity unpinned vs the RTL / xfft_0).  Third set: mode 0xA2, all six
+    sections of the 12th-order Butterworth of fixture G2 (gui.py:108-157 designs them, :1186-1192 keeps two) in Q2.14
+    (fixture G4's `sos_q14`), unsigned-Hann window -- every frame against or_iir_sos_q14."""
     torch = torch_mod
     gen = torch.Generator(device="cuda").manual_seed(2 + int(full_scale))
     B = 4096
     lo, hi = (-32768, 32768) if full_scale else (-2048, 2048)
     x = torch.randint(lo, hi, (B, N), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
     ch.reserve(B)
+    sos, wm = None, 0
     if coeffs == "gui":
         ch.load_coeffs_q7(GUI_UPLOAD)
         cmd, c12 = 0xA1, GUI_UPLOAD
+    elif coeffs == "wide":
+        sos, wm = load_golden("g4_q15_frames.npz")["sos_q14"], 1
+        assert sos.shape == (6, 6)
+        ch.load_sos_q14(sos)
+        ch.set_window_mode_q15(wm)
+        cmd, c12 = 0xA2, None
     else:
         cmd, c12 = 0x00, None
     ch.set_filter_mode(cmd)
@@ -351,7 +366,7 @@ def test_config4_whole_batch(ch, torch_mod, oracle, full_scale, coeffs):
     tm = ch.filter_q15(x).cpu().numpy()
     xh = x.cpu().numpy()
     for a in range(0, B, 512):                                         # the oracle in slices: bounded host memory
-        ref_iq, ref_t = oracle.chain_q15(xh[a:a + 512], None, 0, cmd, c12, None, want_time=True)
+        ref_iq, ref_t = oracle.chain_q15(xh[a:a + 512], None, wm, cmd, c12, sos, want_time=True)
         bad_t = np.nonzero((tm[a:a + 512] != ref_t).any(axis=1))[0]
         bad = np.nonzero((iq[a:a + 512] != ref_iq).reshape(ref_iq.shape[0], -1).any(axis=1))[0]
         assert bad_t.size == 0, f"time series differs in frames {a + bad_t[:8]}"

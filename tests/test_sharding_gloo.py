@@ -100,6 +100,10 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] >= 1
     assert line["per_rank_kernel_ms"] == [2.0, 4.0]
     assert line["launches_in_flight"] == 2
+    # the host cost of a process call is the MAX over ranks; the measured blocks of a GPU line (the other BASELINE
+    # configurations, the roofline, the ordered-mode figures) never appear in a stub line
+    assert line["host_us_per_call"]["ordered"] == 20.0 and line["host_us_per_call"]["headline_mode"] == 20.0
+    assert not {"configs", "roofline", "ordered", "extras"} & set(line)
 
 
 def test_bench_under_torchrun_env_and_mismatch():
@@ -107,6 +111,7 @@ def test_bench_under_torchrun_env_and_mismatch():
     mismatch is an error instead of a silent n_gpus = 1."""
     rc, lines, err = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "0"], {})
     assert rc == 0 and lines[0]["n_gpus"] == 1, err
+    assert "configs" not in lines[0] and lines[0]["host_us_per_call"]["ordered"] == 10.0
     rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and not lines and "WORLD_SIZE" in err
     port = _free_port()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of alternative builds of the library in one process, interleaved rounds.
-usage: ab_libs.py libA.so libB.so[@ovD] ...   (paths relative to the package dir; "@ov2" = overlap depth 2 on that
-handle, sa_set_overlap: timed with a flush before the final synchronisation)"""
+usage: [SA_B=frames] ab_libs.py libA.so libB.so[@ovD] ...   (paths relative to the package dir; "@ov2" = overlap depth 2
+on that handle, sa_set_overlap: timed with a flush before the final synchronisation; SA_B = batch size, default 4096:
+the rotating buffers are slices of one 4096-frame pool, so small batches still stream from HBM)"""
 import ctypes as C
 import os
 import sys
@@ -14,17 +15,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "fpga_real_time_fft_analyzer_amd")
 sos = np.ascontiguousarray(np.load(os.path.join(ROOT, "tests", "golden", "g2_config1.npz"))["sos"], np.float64)
-B = 4096
+B = int(os.environ.get("SA_B", "4096"))
+POOL = max(B, 4096)
 gen = torch.Generator(device="cuda").manual_seed(1)
 n = torch.arange(16384, device="cuda", dtype=torch.float32)
-fb = torch.rand(B, 1, generator=gen, device="cuda") * 0.44 + 0.01
-x = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(B, 16384, generator=gen, device="cuda")).contiguous()
+fb = torch.rand(POOL, 1, generator=gen, device="cuda") * 0.44 + 0.01
+pool = (0.8 * torch.sin(2 * np.pi * fb * n) + 0.05 * torch.randn(POOL, 16384, generator=gen, device="cuda")).contiguous()
+x = pool[:B]
 out = torch.empty_like(x)
 # ROT buffer pairs used round-robin in the timed loops: one pair (256 MiB in) would sit in the 256 MB Infinity
 # Cache from launch to launch and the comparison would be about the cache, not HBM
 ROT = int(os.environ.get("SA_ROT", "4"))
-xs = [x] + [x.clone() for _ in range(ROT - 1)]
-outs = [out] + [torch.empty_like(x) for _ in range(ROT - 1)]
+if B < 4096:                                   # 4 x 4096 frames of input and output, cut into B-frame slices
+    pools = [pool] + [pool.clone() for _ in range(3)]
+    opools = [torch.empty_like(pool) for _ in range(4)]
+    xs = [p[j:j + B] for p in pools for j in range(0, POOL - B + 1, B)]
+    outs = [p[j:j + B] for p in opools for j in range(0, POOL - B + 1, B)]
+    ROT = len(xs)
+else:
+    xs = [x] + [x.clone() for _ in range(ROT - 1)]
+    outs = [out] + [torch.empty_like(x) for _ in range(ROT - 1)]
 libs = []
 for name in sys.argv[1:]:
     # "lib.so:VAR=value" sets an environment variable while that library's handle is created (plan-time switches)
@@ -56,7 +66,7 @@ for name in sys.argv[1:]:
         name = f"{name}#{len(libs)}"            # the same build on a further handle
     libs.append((name, L, h))
 st = torch.cuda.current_stream().cuda_stream
-ROUNDS, REPS = 12, 40
+ROUNDS, REPS = 12, (40 if B >= 4096 else 200)
 for mode in (0xA1, 0xB1):
     res, ref = {}, None
     # sustained pre-warm so that every build is measured at the settled clock
