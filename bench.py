@@ -282,6 +282,7 @@ class GpuWorkload:
         """Host time of one process call (Python wrapper + ctypes + launch) while the GPU is still busy with the calls
         before it: n calls in a row without a wait in between (n x 128 us of device work against well under a
         millisecond of host work, so the queue never fills)."""
+        self.step()                   # (the first overlapped call after a change of mode probes its streams once: ~1 ms)
         self.sync()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -292,11 +293,11 @@ class GpuWorkload:
 
     def _measure(self, fn, frames, bytes_per_frame, steps, depth, timed_calls=True):
         """One configuration: `depth` launches in flight, 0.25 s of untimed conditioning (as the headline gets), then
-        `steps` steps between two synchronisations; in the ordered mode also the device time of every call."""
+        `steps` steps between two synchronisations (the wall figure, launch timing OFF: a timed launch carries a start
+        event, which costs a small batch several microseconds per launch); in the ordered mode a second, shorter train
+        with launch timing on gives the device time of a call."""
         ch = self.ch
         ch.set_overlap(depth)
-        if depth == 1 and timed_calls:
-            ch.set_profiling(steps)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.25:
             for _ in range(10):
@@ -311,14 +312,18 @@ class GpuWorkload:
                "achieved_GBps": round(frames * bytes_per_frame / dt / 1e9, 1),
                "frac": round(frames * bytes_per_frame / dt / 1e9 / HBM_PEAK_GBS, 4)}
         if depth == 1 and timed_calls:
-            ms = ch.profile_read(steps)
+            n = max(8, steps // 4)
+            ch.set_profiling(n)
+            for _ in range(n):
+                fn()
+            ms = ch.profile_read(n)
             ch.set_profiling(0)
             res["call_ms_avg"] = round(float(np.mean(ms)), 4)
             res["call_frac"] = round(frames * bytes_per_frame / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         ch.set_overlap(1)
         return res
 
-    def configs(self):
+    def configs(self, with_overlap=True):
         """The other single-GPU configurations of BASELINE.json, in the default line (the driver passes no flag).
         configs[1]: B = 256 fp32 frames, Hann + FFT + magnitude, IIR bypassed -- the board's power-on mode
         (new/command_control.vhd:31); 64 rotating 256-frame slices of the headline's buffers (1 GiB in, 1 GiB out: a
@@ -354,7 +359,7 @@ class GpuWorkload:
         r["bytes_per_frame"] = BYTES_PER_FRAME_Q15
         r["workload"] = (f"BASELINE.json configs[3]: batch={B} x 16K int16 (12-bit samples), FPGA-exact window + default "
                          f"ALPHA/BETA cascade + fixed-point FFT, IQ frames out; call = cascade kernel + FFT kernel")
-        if R > 2:
+        if R > 2 and with_overlap:
             r["overlap2"] = self._measure(qstep, B, BYTES_PER_FRAME_Q15, 40, 2)
             ch.reserve(B)
         out["config4_q15_default"] = r
@@ -362,8 +367,10 @@ class GpuWorkload:
         del xqs, oqs
         return out
 
-    def extras(self, steps):
-        """Bypass (config 2) and Q15 (config 4) figures next to the headline; not the bench line's value."""
+    def extras(self, steps, with_overlap=True):
+        """Bypass (config 2) and Q15 (config 4) figures next to the headline; not the bench line's value.
+        with_overlap = False (`--overlap 1`): every launch of the process is stream-ordered, so that a kernel trace of
+        the run holds ordered launches only."""
         torch, ch, dev, B, R, gen = self.torch, self.ch, self.dev, self.B, self.R, self.gen
         out = {}
 
@@ -384,7 +391,7 @@ class GpuWorkload:
         out["config2_bypass_b256"] = {"frames_per_s": 256 / dt, "GBps": 256 * BYTES_PER_FRAME_F32 / dt / 1e9}
         dt = time_it(self.step, steps)
         out["bypass_b4096"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
-        if R > 3:                # the same with three launches in flight (the bypassed chain is not at the power cap)
+        if R > 3 and with_overlap:   # the same with three launches in flight (the bypassed chain is not at the power cap)
             ch.set_overlap(3)
             dt = time_it(self.step, steps)
             out["bypass_b4096_overlap3"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_F32 / dt / 1e9}
@@ -407,7 +414,7 @@ class GpuWorkload:
                 ch.set_filter_mode(cmd)
                 dt = time_it(qstep, 5)
                 out[name + tag] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
-            if R > 2:              # the wide cascade (0xA2, all six designed sections in Q2.14) with two launches in flight
+            if R > 2 and with_overlap:   # the wide cascade (0xA2, all six designed sections in Q2.14) with two launches in flight
                 ch.set_overlap(2)
                 ch.reserve(B)
                 ch.set_filter_mode(0xA2)
@@ -415,7 +422,7 @@ class GpuWorkload:
                 out["q15_wide_6sec" + tag + "_overlap2"] = {"frames_per_s": B / dt, "GBps": B * BYTES_PER_FRAME_Q15 / dt / 1e9}
                 ch.set_overlap(1)
             for depth in (2, 3):   # config 4 with launches in flight: the FFT of batch k under the filter of batch k+1
-                if R <= depth:
+                if R <= depth or not with_overlap:
                     continue
                 ch.set_overlap(depth)
                 ch.reserve(B)
@@ -437,7 +444,7 @@ class GpuWorkload:
             k[0] += 1
         dt = time_it(istep, steps)
         out["float_chain_from_int16"] = {"frames_per_s": B / dt, "GBps": B * (32768 + 65536) / dt / 1e9}
-        if R > 2:
+        if R > 2 and with_overlap:
             ch.set_overlap(2)
             dt = time_it(istep, steps)
             out["float_chain_from_int16_overlap2"] = {"frames_per_s": B / dt, "GBps": B * (32768 + 65536) / dt / 1e9}
@@ -664,7 +671,7 @@ def main():
 
     # the other single-GPU configurations of BASELINE.json, beside the headline in the default line, BEFORE the power
     # sample (2.5 s at the cap leave the chip hotter than the headline found it)
-    configs = wl.configs() if (world == 1 and rank == 0 and not stub and not a.no_configs) else {}
+    configs = wl.configs(a.overlap > 1) if (world == 1 and rank == 0 and not stub and not a.no_configs) else {}
 
     # Package power and shader clock while the headline mode runs (untimed repeat of the step loop, rank 0's card only):
     # the launch sits at the power cap and the clock is what gives (profiles/r3_power_clock.txt), which is what bounds
@@ -677,7 +684,7 @@ def main():
         if power:                        # energy of one step at that power: what a power-limited launch is made of
             power["mj_per_step"] = round(power["socket_w"] * elapsed / a.steps * 1e3, 1)
 
-    extras = wl.extras(a.steps) if (a.extras and rank == 0 and not stub) else {}
+    extras = wl.extras(a.steps, a.overlap > 1) if (a.extras and rank == 0 and not stub) else {}
 
     if rank == 0:
         # HBM traffic per launch: FETCH_SIZE (doubled, gfx950) + WRITE_SIZE from the committed separate
@@ -685,7 +692,7 @@ def main():
         # read inside the timed process, so this is a constant quoted from that profile -- `traffic_source`
         # says which -- and null when the profile was taken at another batch size.
         traffic, traffic_src, valu_busy = None, None, None
-        for name in ("r3_pmc_traffic.json",):        # regenerated with the round's kernel (tools/pmc_profile.sh)
+        for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):   # regenerated with the round's kernel (tools/pmc_profile.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pj = json.load(fh)

@@ -46,6 +46,8 @@ constexpr int kScrOff = kLdsComplex * 8;              // scan scratch: 6 section
 constexpr int kSideOff = kScrOff + 6 * 16 * 8;        // one complex side slot (Z[6144])
 constexpr int kLaneOff = kSideOff + 16;               // (two complex side slots) then the per-lane matrices P2^i: 6 x 16 x float4
 constexpr int kLdsBytes = kLaneOff + 6 * 16 * 16;
+constexpr int kLdsOneRound = 65536;                   // the bypassed chain at small batches: a whole float32 frame at once
+static_assert(kLdsBytes <= kLdsOneRound, "the exchange images and side slots live inside the one-round image");
 
 // The two-component scan state travels as ONE register pair and every 2x2 matrix is stored column-major (a column is
 // an aligned register pair): a matrix-vector product is two packed FMAs, column x broadcast component -- for wave-uniform
@@ -218,15 +220,8 @@ __device__ __forceinline__ void stage_in_chunks(const float *__restrict__ xin, c
         // DMA (vmcnt) and, before overwriting the rows with round 1, for its own reads of round 0 (lgkmcnt).
         // Three barriers fewer per frame; a wave delayed on its SIMD no longer holds the other three here.
         if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if SA_AB_PROBE == 1                    // timing probes (results invalid), profiles/r3_timing_probes.txt: round 1 of the stage-in skipped
-        if (h == 0)
-#elif SA_AB_PROBE == 6                  // probe 6: no input traffic at all
-        if (false)
-#endif
-        {
-            dma_chunk_half(xin, h, smem, lane, wave);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        dma_chunk_half(xin, h, smem, lane, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // nothing of the window arithmetic below may be scheduled above the wait (register-only instructions do
         // cross an asm statement): computed early, the 32 window values of the round sit in registers and spill
         __builtin_amdgcn_sched_barrier(0);
@@ -377,11 +372,7 @@ __device__ __forceinline__ void iir_section(v2f (&d)[32], const SecT &k, const S
     if ((lane & 15) == 15) scr_s[row] = make_float2(T.x, T.y);
     const v2f e = {row_shr<1>(T.x), row_shr<1>(T.y)};            // exclusive: state before this thread, row-local
     SA_STAMP_SEC(4);
-#ifdef SA_AB_NO_SCAN_BARRIER          // timing probe only (results invalid): what the six scan barriers of a frame cost at most
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     lds_barrier();
-#endif
     SA_STAMP_SEC(5);
     v2f cst;
     if (flags & SA_IIR_SKIP_ROWSCAN) {
@@ -539,7 +530,11 @@ __device__ __forceinline__ int zpos_partner(int w) { return zrow_pos(w, (4 + (w 
 
 // ---------------------------------------------------------------------------------------------
 // One frame: window -> IIR -> FFT -> split -> store.
-template <int NSEC, bool UNIT, int OUT, bool WINGEN, typename PlanT>
+// ONE_ROUND (bypassed chain on float32 frames, small batches only: sa_launch_chain_f32): the whole 64 KiB frame is
+// requested at once into a 64 KiB LDS image instead of two half-frame rounds -- one HBM round trip and one barrier
+// fewer per frame, at two workgroups per CU instead of four, which costs nothing while the batch leaves the CUs
+// half empty anyway (B <= 512: at most two workgroups per CU either way).
+template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool ONE_ROUND, typename PlanT>
 __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM void *__restrict__ out,
                                             const int f, unsigned char *smem,
                                             const float4 *__restrict__ winb, const float4 *__restrict__ twT,
@@ -571,9 +566,7 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
         stage_in_chunks<WINGEN>(xin, reinterpret_cast<const float4 *>(lanetab->win_t), lanetab, smem, t, d);
 #endif
         SA_STAMP(1);
-#if SA_AB_PROBE != 3                    // probe 3: the whole cascade skipped (window -> FFT)
         iir_cascade<NSEC, UNIT>(d, ka, lanetab, scr, t);
-#endif
         SA_STAMP(2);
         // exchange to the pass-A layout in two rounds (m1 < 16, m1 >= 16): the owners of the half
         // write z[32 t' + j] = (x[2j], x[2j+1]) at 33 t' + j; everybody reads z[256 m1 + t].  Real and
@@ -630,26 +623,29 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
             }
         }
 #else
+        constexpr int kRounds = ONE_ROUND ? 1 : 2;
+        constexpr int kSlabs = 32 / kRounds / 2;           // 1 KiB DMA requests per wave and round: 8 (two rounds) or 16
+        constexpr int kPairs = 16 / kRounds;               // window quads (two complex points each) per thread and round
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kRounds; ++h) {
             if (h == 1) __syncthreads();
             __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = wave * 8 + i;
+            for (int i = 0; i < kSlabs; ++i) {
+                const int n = wave * kSlabs + i;
                 const float *src = xin + h * 8192 + n * 256 + lane * 4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(smem + n * 1024), 16, 0, SA_DMA_AUX);
             }
             __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
+            __syncthreads();          // (the round's window values requested in front of this barrier: 2 % slower, round 4)
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp) {
-                const float4 w = winb[(8 * h + pp) * 256 + t];
+            for (int pp = 0; pp < kPairs; ++pp) {
+                const float4 w = winb[(kPairs * h + pp) * 256 + t];
                 const cf z0 = ldc[256 * (2 * pp) + t];
                 const cf z1 = ldc[256 * (2 * pp + 1) + t];
-                a[safft::brev(16 * h + 2 * pp, 5)] = {z0.x * w.x, z0.y * w.y};
-                a[safft::brev(16 * h + 2 * pp + 1, 5)] = {z1.x * w.z, z1.y * w.w};
+                a[safft::brev(2 * kPairs * h + 2 * pp, 5)] = {z0.x * w.x, z0.y * w.y};
+                a[safft::brev(2 * kPairs * h + 2 * pp + 1, 5)] = {z1.x * w.z, z1.y * w.w};
             }
         }
 #endif
@@ -665,9 +661,13 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
     float4 an[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) an[i] = twT[i * 256 + t];
-#if SA_AB_PROBE != 4
+    // The split-step anchors W_16384^(4 t), W_16384^(4 (t + 1)) ride along for the full-spectrum output (round 4: requested
+    // right before the split step their L2 round trip was exposed once per frame -- 103.8 -> 97.0 us on the bypassed chain
+    // at B = 4096, 11.5 -> 10.8 us at B = 256, -1 % with the cascade, gpurun_out/ab_an5.txt).  The half-spectrum variants
+    // keep the late request: four more registers through three FFT passes make them spill.
+    float4 an5_early = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (OUT == SA_OUT_MAG_FULL) an5_early = twT[5 * 256 + t];
     safft::fft_dit<32>(a);
-#endif
     {
         const cf wb[8] = {{1.f, 0.f}, {an[0].x, an[0].y}, {an[0].z, an[0].w}, {an[1].x, an[1].y},
                           {an[1].z, an[1].w}, {an[2].x, an[2].y}, {an[2].z, an[2].w}, {an[3].x, an[3].y}};
@@ -694,12 +694,8 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
     }
     SA_STAMP_FFT(5);
     // ---- pass B: 16-point FFT over a, twiddle W_256^(b*c)
-#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[0]);
-#endif
-#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[1]);
-#endif
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {                       // twB4[pp][b] = (W_256^(2pp * b), W_256^((2pp+1) * b))
         const float4 w = twB[pp * 16 + lo];
@@ -732,20 +728,16 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
     }
     SA_STAMP_FFT(7);
     // ---- pass C: 16-point FFT over b -> d;  Z[k1 + 32c + 512d], k1 = 16q + 4 wave + kq, c = lo
-#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[0]);
-#endif
-#if SA_AB_PROBE != 4
     safft::fft_dit<16>(p[1]);
-#endif
     SA_STAMP_FFT(8);
     // split-step anchors: W_16384^(4 t) and the right-hand neighbour's W_16384^(4 (t + 1)), (1, 0) for t = 255 (its
-    // neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0).  Requested here, through an opaque copy
-    // of the thread index: loaded with the other anchors the four registers sit through three FFT passes (and spill in
-    // the half-spectrum variants).
+    // neighbour is thread 0 of the next block of 1024 bins, whose anchor is W^0).  Half-spectrum outputs request them
+    // here, through an opaque copy of the thread index (see an5_early above).
     int ts = t;
     asm volatile("" : "+v"(ts));
-    const float4 an5 = twT[5 * 256 + ts];
+    float4 an5 = an5_early;
+    if constexpr (OUT != SA_OUT_MAG_FULL) an5 = twT[5 * 256 + ts];
     const cf wP = {an5.x, an5.y}, wPn = {an5.z, an5.w};
     // ---- natural-order image + split step, two rounds: round 0 = d in {0..3,12..15} (bins k < 2048
     //      and their partners), round 1 = d in {4..11}.  Z[2048] and Z[6144] sit on the seam and
@@ -877,7 +869,7 @@ __device__ __forceinline__ void chain_frame(const sa_in_t *__restrict__ in, SA_I
 #endif
 }
 
-template <int NSEC, bool UNIT, int OUT, bool WINGEN>
+template <int NSEC, bool UNIT, int OUT, bool WINGEN, bool ONE_ROUND = false>
 __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const sa_in_t *__restrict__ in, SA_IN_SCALE_PARAM
                                                                  void *__restrict__ out, int batch,
                                                                  const float4 *__restrict__ winb,
@@ -890,7 +882,7 @@ __global__ __launch_bounds__(kThreads, 4) void chain_f32_kernel(const sa_in_t *_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int f = blockIdx.x;
     if (f >= batch) return;
-    chain_frame<NSEC, UNIT, OUT, WINGEN>(in, SA_IN_SCALE_ARG out, f, smem, winb, twT, twB, twC, lanetab, ka);
+    chain_frame<NSEC, UNIT, OUT, WINGEN, ONE_ROUND>(in, SA_IN_SCALE_ARG out, f, smem, winb, twT, twB, twC, lanetab, ka);
 }
 
 // Window (+ IIR) only: the FFT input time series (debug / parity output, not a hot path: two workgroups per CU are
@@ -968,6 +960,31 @@ hipError_t launch_nsec(const sa_in_t *in, const float in_scale, void *out, int b
 {
     const dim3 grid(batch), block(kThreads);
     hipError_t e = hipSuccess;
+#if !SA_F32_INPUT_I16
+    // Small batches of the bypassed chain (the board's power-on mode, new/command_control.vhd:31; BASELINE config 2 is
+    // B = 256): at most two workgroups per CU are resident whatever the kernel asks for, so the frame comes in as ONE
+    // 64 KiB round (chain_frame<ONE_ROUND>).  Same arithmetic, same results.
+    // A/B in one process (gpurun_out/ab_oneround.txt): 11.0 -> 10.8 us at B = 256, 15.5 -> 15.3 us at B = 512.
+    constexpr int kOneRoundMax = 512;
+    if constexpr (NSEC == 0) if (batch <= kOneRoundMax && out_kind != SA_OUT_TIME) {
+#define SA_LAUNCH1(OUTK)                                                                               \
+    do {                                                                                               \
+        auto kern = chain_f32_kernel<0, false, OUTK, false, true>;                                     \
+        e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(kern), kLdsOneRound);                   \
+        if (e != hipSuccess) return e;                                                                 \
+        hipExtLaunchKernelGGL(kern, grid, block, kLdsOneRound, stream, ev.start, ev.stop, 0, in, out, batch, tb.win_b, tb.twT, \
+                              tb.twB, tb.twC, tb.lanetab, ka);                                         \
+    } while (0)
+        switch (out_kind) {
+            case SA_OUT_MAG_FULL: SA_LAUNCH1(SA_OUT_MAG_FULL); break;
+            case SA_OUT_MAG_HALF: SA_LAUNCH1(SA_OUT_MAG_HALF); break;
+            case SA_OUT_SPEC_HALF: SA_LAUNCH1(SA_OUT_SPEC_HALF); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef SA_LAUNCH1
+        return hipGetLastError();
+    }
+#endif
 #define SA_LAUNCH(OUTK)                                                                                \
     do {                                                                                               \
         auto kern = ka.wingen ? chain_f32_kernel<NSEC, UNIT, OUTK, (NSEC > 0)>                          \

@@ -1,6 +1,5 @@
-// chain_f32_dev.hpp -- device helpers shared by the float-path kernels (chain_f32.hip: 256 threads per frame;
-// chain_f32_w8.hip: 512 threads per frame, 8 waves per SIMD): LDS-only barrier, DPP row shifts, nontemporal
-// stores, the split step of the packed real FFT and its output layouts.
+// chain_f32_dev.hpp -- device helpers of the float-path kernels (chain_f32.hip): LDS-only barrier, DPP row shifts,
+// nontemporal stores, the split step of the packed real FFT and its output layouts.
 #pragma once
 #include "sa_common.hpp"
 #include "fft_regs.hpp"
@@ -11,9 +10,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
-#ifndef SA_AB_PROBE
-#define SA_AB_PROBE 0         // timing probes of A/B builds (results invalid); 0 = the product
-#endif
 #ifndef SA_DMA_AUX
 #define SA_DMA_AUX 2          // cache policy bits of the input LDS-DMA: 2 = nontemporal (a frame is read once); 0 in A/B
                               // builds: 132.2 -> 130.3 us stream-ordered, no difference with two launches in flight
@@ -46,10 +42,6 @@ __device__ unsigned long long *g_sa_stamps = nullptr;
 // on vmcnt.)
 __device__ __forceinline__ void lds_barrier()
 {
-#if defined(SA_AB_PROBE) && SA_AB_PROBE == 5      // timing probe (results invalid): no workgroup barrier anywhere
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return;
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
@@ -73,9 +65,6 @@ typedef float f4nt __attribute__((ext_vector_type(4)));
 typedef float f2nt __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_nt(float *p, float a, float b, float c, float d)
 {
-#if SA_AB_PROBE == 2                    // timing probe (results invalid): the output stores never execute
-    if (!(a == 12345.678f)) return;
-#endif
     __builtin_nontemporal_store(f4nt{a, b, c, d}, reinterpret_cast<f4nt *>(p));
 }
 __device__ __forceinline__ void store_nt(float2 *p, float a, float b)

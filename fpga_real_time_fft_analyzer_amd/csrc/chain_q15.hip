@@ -568,9 +568,6 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
     SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
 
-#ifdef SA_AB_Q15_PRIO              // A/B builds only: the cascade's lone wave ahead of whatever shares its SIMD
-    __builtin_amdgcn_s_setprio(SA_AB_Q15_PRIO);
-#endif
     // taps, pre-shifted by 9; identity = (128 x) >> 7
     int cB2 = 128 << 9, cB1 = 0, cB0 = 0, nA0 = 0, nA1 = 0;
     if (l16 >= 1 && l16 <= 6) {
@@ -755,9 +752,6 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
     if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
     SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
 
-#ifdef SA_AB_Q15_PRIO              // A/B builds only: the cascade's lone wave ahead of whatever shares its SIMD
-    __builtin_amdgcn_s_setprio(SA_AB_Q15_PRIO);
-#endif
     W14Taps taps = w14_taps(16384, 0, 0, 0, 0);              // identity: (16384 x + 8192) >> 14 = x exactly
     if (l16 >= 1 && l16 <= prm.nsec_wide) {
         const int16_t *c = &prm.sos_q14[(l16 - 1) * 6];      // scipy row order [b0, b1, b2, a0, a1, a2], a0 ignored (= 1.0)
@@ -1047,12 +1041,7 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
     } else {
         // B1 = 0 in both coefficient sets (wire order b0,b1,b2,a0,a1,a2 per set): the seven-instruction step
         const bool nob1 = p.c12[1] == 0 && p.c12[7] == 0;
-#ifdef SA_AB_Q7_NO_ELISION            // A/B builds only
-        const bool use_nb1 = false;
-#else
-        const bool use_nb1 = nob1;
-#endif
-        if (use_nb1)
+        if (nob1)
             hipExtLaunchKernelGGL(filter_q7_kernel<true>, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
         else
             hipExtLaunchKernelGGL(filter_q7_kernel<false>, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);

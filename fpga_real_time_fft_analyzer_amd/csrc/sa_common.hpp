@@ -79,46 +79,6 @@ struct SaIirLaneTab {
     float win_t[SA_NPTS];
 };
 
-// ---- the same plan for the 512-thread kernels (chain_f32_w8.hip: 8 waves per SIMD).  Thread t owns the two
-// consecutive 16-sample chunks [32t, 32t+16) and [32t+16, 32t+32); a 16-lane row covers 512 samples, a frame has 32
-// rows.  Every 2x2 matrix is stored COLUMN-major (m00, m10, m01, m11): a column is an aligned register pair, and
-// a matrix-vector product is two packed FMAs (column * broadcast component), for wave-uniform matrices straight
-// from their scalar registers.
-#define SA8_CHUNK 16
-#define SA8_NTHREADS 512
-#define SA8_ROWS 32
-struct SaIirSecK8 {
-    float mnext[SA8_CHUNK][2]; // predictor taps (m1, m2) of the NEXT section (zero for the last one)
-    float c[5];                // b0,b1,b2,a1,a2
-    int flags;                 // bit i (0..3): in-row scan level 2^i skipped; SA_IIR_SKIP_ROWSCAN: Prow below resolution
-    float pad[2];
-    float pc[4];               // Pc = A^16 (one chunk)
-    float mback[4];            // T^-1: pole coordinates -> DF2T states
-    float plev[4][4];          // P2^(1,2,4,8), P2 = A^32 (one thread)     in-row scan
-    float prow[5][4];          // Prow^(1,2,4,8,16), Prow = A^512 (one row)  scan over the 32 rows (pairs of rows)
-};
-
-struct SaIirK8 {
-    int nsec, unit;            // as SaIirK
-    float gain;
-    int wingen;
-    float m0[SA8_CHUNK][2];    // predictor taps of section 0
-    SaIirSecK8 sec[SA_MAXSEC];
-};
-
-// device-memory part:
-//   p[s][i]  = P2^i (column-major), i = lane inside its 16-lane row
-//   wgen[t]  = (P_A, P_B, Q_A, Q_B): W[32t + 16h + j] = wg0 + P_h wcs[j][0] + Q_h wcs[j][1]   (in-place window)
-//   win_t    = 0.5 * window * G for any other window: win_t[j2][t] = (w[32t+2j2], w[32t+16+2j2], w[32t+2j2+1], w[32t+16+2j2+1])
-struct SaIirLaneTab8 {
-    float p[SA_MAXSEC][16][4];
-    float wgen[SA8_NTHREADS][4];
-    float wcs[SA8_CHUNK][2];
-    float wg0;
-    float pad[3];
-    float win_t[SA_NPTS];
-};
-
 // Integer-path parameters passed by value (kernarg => stream-ordered for free).
 struct SaQ15Params {
     int win_mode;          // SA_WIN_*
@@ -147,12 +107,6 @@ struct SaF32Tables {
                                //            factor of the split-step twiddles
     const SaIirLaneTab *lanetab;   // device
     const SaIirK *iir;             // HOST pointer, copied into the kernel arguments (null = no IIR)
-    // 512-thread kernels (chain_f32_w8.hip)
-    const float4 *twT8;        // [4][512]   per-thread anchors, u = t >> 1, g = t >> 1, half = t & 1:
-                               //   row 0: W4096^(u), W4096^(2u)   row 1: W4096^(3u), W4096^(4u)   row 2: W4096^(8u), W4096^(12u)
-                               //   row 3: W_16384^(4g + 4096 half) and the same for the next group (g + 1; g = 255: 4096 half)
-    const SaIirLaneTab8 *lanetab8; // device
-    const SaIirK8 *iir8;           // HOST pointer (null = no IIR)
 };
 
 // Events of a launch (either may be null), attached to the dispatch packet itself by hipExtLaunchKernel: no marker
@@ -167,10 +121,6 @@ hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_ki
 // the same chain on int16 samples (chain_f32_i16.hip): x = float(sample) * in_scale, then exactly the float32 path
 hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &t,
                                    hipStream_t stream, SaLaunchEv ev);
-// the 512-thread form (chain_f32_w8.hip): IIR modes with the three spectrum outputs; returns hipErrorNotSupported
-// for anything else (the caller then takes sa_launch_chain_f32)
-hipError_t sa_launch_chain_f32_w8(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
-                                  hipStream_t stream, SaLaunchEv ev);
 
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM

@@ -116,90 +116,6 @@ inline void put_cm(float *dst, const Mat2 &m)      // column-major
     dst[0] = (float)m.a; dst[1] = (float)m.c; dst[2] = (float)m.b; dst[3] = (float)m.d;
 }
 
-#ifdef SA_WITH_W8      // A/B builds with the 512-thread probe kernel (probes/chain_f32_w8.hip) only
-// The plan of the 512-thread kernels (SaIirK8 / SaIirLaneTab8 in sa_common.hpp): same algebra as build_plan below
-// with 16-sample chunks, 32-sample threads, 512-sample rows, matrices column-major.
-void build_plan8(const double *sos_in, int nsec_in, SaIirK8 *plan, SaIirLaneTab8 *lt, const float *half_win,
-                 const double *cosw = nullptr)
-{
-    std::memset(plan, 0, sizeof(*plan));
-    std::memset(lt, 0, sizeof(*lt));
-    double sos[36];
-    bool unit;
-    double gain;
-    const int nsec = normalise_cascade(sos_in, nsec_in, sos, &unit, &gain);
-    plan->nsec = nsec;
-    plan->unit = unit ? 1 : 0;
-    plan->gain = (float)gain;
-    if (half_win)
-        for (int t = 0; t < SA8_NTHREADS; ++t)
-            for (int j2 = 0; j2 < 8; ++j2) {
-                float *o = &lt->win_t[(j2 * SA8_NTHREADS + t) * 4];
-                o[0] = (float)((double)half_win[32 * t + 2 * j2] * gain);
-                o[1] = (float)((double)half_win[32 * t + 16 + 2 * j2] * gain);
-                o[2] = (float)((double)half_win[32 * t + 2 * j2 + 1] * gain);
-                o[3] = (float)((double)half_win[32 * t + 16 + 2 * j2 + 1] * gain);
-            }
-    plan->wingen = 0;
-    if (half_win && cosw) {
-        const double theta = 2.0 * M_PI / (double)(SA_NPTS - 1), S = 0.5 * gain;
-        plan->wingen = 1;
-        lt->wg0 = (float)(S * cosw[0]);
-        for (int t = 0; t < SA8_NTHREADS; ++t)
-            for (int h = 0; h < 2; ++h) {
-                const double a = theta * (double)(32 * t + 16 * h);
-                lt->wgen[t][h] = (float)(-S * cosw[1] * std::cos(a));        // P_A, P_B
-                lt->wgen[t][2 + h] = (float)(S * cosw[1] * std::sin(a));     // Q_A, Q_B
-            }
-        for (int j = 0; j < SA8_CHUNK; ++j) {
-            lt->wcs[j][0] = (float)std::cos(theta * j);
-            lt->wcs[j][1] = (float)std::sin(theta * j);
-        }
-    }
-    auto tiny = [](const Mat2 &m) {
-        const double mx = std::fmax(std::fmax(std::fabs(m.a), std::fabs(m.b)), std::fmax(std::fabs(m.c), std::fabs(m.d)));
-        return mx < 1e-10;
-    };
-    for (int s = 0; s < nsec; ++s) {
-        const double *r = sos + 6 * s;
-        const double b0 = r[0], b1 = r[1], b2 = r[2], a1 = r[4], a2 = r[5];
-        SaIirSecK8 &sp = plan->sec[s];
-        sp.c[0] = (float)b0; sp.c[1] = (float)b1; sp.c[2] = (float)b2; sp.c[3] = (float)a1; sp.c[4] = (float)a2;
-        Mat2 M, T, A;
-        pole_coordinates(a1, a2, &M, &T, &A);
-        put_cm(sp.mback, M);
-        double v0 = T.a * (b1 - a1 * b0) + T.b * (b2 - a2 * b0);      // T Bv
-        double v1 = T.c * (b1 - a1 * b0) + T.d * (b2 - a2 * b0);
-        float (*mdst)[2] = s == 0 ? plan->m0 : plan->sec[s - 1].mnext;
-        for (int j = SA8_CHUNK - 1; j >= 0; --j) {        // m[j] = A^(15-j) T Bv
-            mdst[j][0] = (float)v0;
-            mdst[j][1] = (float)v1;
-            const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
-            v0 = n0; v1 = n1;
-        }
-        const Mat2 Pc = mpow(A, SA8_CHUNK);
-        const Mat2 P2 = mul(Pc, Pc);
-        const Mat2 Prow = mpow(P2, 16);
-        put_cm(sp.pc, Pc);
-        sp.flags = tiny(Prow) ? SA_IIR_SKIP_ROWSCAN : 0;
-        Mat2 q = P2, qr = Prow;
-        for (int i = 0; i < 5; ++i) {
-            if (i < 4) {
-                put_cm(sp.plev[i], q);
-                if (tiny(q)) sp.flags |= 1 << i;
-                q = mul(q, q);
-            }
-            put_cm(sp.prow[i], qr);
-            qr = mul(qr, qr);
-        }
-        Mat2 pw = {1, 0, 0, 1};
-        for (int i = 0; i < 16; ++i) {
-            put_cm(lt->p[s][i], pw);
-            pw = mul(pw, P2);
-        }
-    }
-}
-#endif
 
 // Build the predict/scan/recurse plan for an a0-normalised SOS (rows b0,b1,b2,1,a1,a2), double in.
 // The kernels are compiled for 2, 4 and 6 sections; shorter cascades are padded with identity
@@ -331,10 +247,6 @@ struct sa_handle {
     std::vector<int16_t> rom;
     SaIirK plan_default{}, plan_custom{};
     SaIirLaneTab lt_default{}, lt_custom{};
-#ifdef SA_WITH_W8
-    SaIirK8 plan8_default{}, plan8_custom{};          // the same cascades in the 512-thread probe kernels' layout
-    SaIirLaneTab8 lt8_default{}, lt8_custom{};
-#endif
     std::vector<float> half_win;           // 0.5 * float window, natural order
     bool win_is_cos = true;                // the float window is a0 - a1 cos(2 pi n / (N-1)) (default: Hann)
     double win_cos[2] = {0.5, 0.5};
@@ -346,8 +258,6 @@ struct sa_handle {
     float4 *d_twT = nullptr, *d_twB = nullptr;
     float2 *d_twC = nullptr;
     SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
-    SaIirLaneTab8 *d_lt8_default = nullptr, *d_lt8_custom = nullptr;
-    float4 *d_twT8 = nullptr;
     int16_t *d_rom = nullptr;
     uint2 *d_twq = nullptr;          // SA-FXFFT-1 twiddles, {(wr, wi), (-wi, wr)} packed int16 pairs
     // Q15 IIR workspace, one per launch slot (slot 0 = ordered mode; overlap mode uses slots 0..depth-1).  A
@@ -494,8 +404,7 @@ int pick_stream(sa_handle *h, const hipStream_t *avoid, int navoid, hipStream_t 
     return rc;
 }
 
-constexpr size_t kStageBytes = sizeof(SaIirLaneTab8) > sizeof(SaIirLaneTab) ? sizeof(SaIirLaneTab8) : sizeof(SaIirLaneTab);
-// (the probe kernels' table is the larger one; sized for it in every build so that the staging ring does not change)
+constexpr size_t kStageBytes = sizeof(SaIirLaneTab);      // the largest table a handle uploads
 static_assert(kStageBytes >= sizeof(float) * SA_NPTS, "a staging slot holds any table of the handle");
 
 // Control-plane calls change host state and device tables; a process call that is being captured into a hipGraph
@@ -644,9 +553,6 @@ int begin_call(sa_handle *h, hipStream_t user, CallCtx *c)
     }
     // a captured record would tie the event to the graph; replays are ordered by the caller (include/specan.h)
     c->stop = c->captured ? nullptr : h->launched;
-#ifdef SA_AB_NO_STOP_EVENT               // A/B builds only: prices the stop event of the ordered mode
-    c->stop = nullptr;
-#endif
     return SA_OK;
 }
 
@@ -815,10 +721,6 @@ int set_custom_plan(sa_handle *h, const double *sos_norm, int nsec)
     h->nsec_custom = nsec;
     const double *cw = h->win_is_cos ? h->win_cos : nullptr;
     build_plan(h->sos_custom, nsec, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
-#ifdef SA_WITH_W8
-    build_plan8(h->sos_custom, nsec, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), cw);
-    { const int rc8 = upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8)); if (rc8 != SA_OK) return rc8; }
-#endif
     return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
@@ -831,14 +733,6 @@ int rebuild_plans(sa_handle *h)
     int rc = upload(h, h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab));
     if (rc != SA_OK) return rc;
     build_plan(h->sos_custom, h->nsec_custom, &h->plan_custom, &h->lt_custom, h->half_win.data(), cw);
-#ifdef SA_WITH_W8
-    build_plan8(sos, 6, &h->plan8_default, &h->lt8_default, h->half_win.data(), cw);
-    rc = upload(h, h->d_lt8_default, &h->lt8_default, sizeof(SaIirLaneTab8));
-    if (rc != SA_OK) return rc;
-    build_plan8(h->sos_custom, h->nsec_custom, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), cw);
-    rc = upload(h, h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8));
-    if (rc != SA_OK) return rc;
-#endif
     return upload(h, h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab));
 }
 
@@ -887,11 +781,6 @@ int sa_create(int device, sa_handle **out)
     SA_HIPC(hipMalloc(&h->d_twC, sizeof(float2) * 25));
     SA_HIPC(hipMalloc(&h->d_lt_default, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
-#ifdef SA_WITH_W8
-    SA_HIPC(hipMalloc(&h->d_lt8_default, sizeof(SaIirLaneTab8)));
-    SA_HIPC(hipMalloc(&h->d_lt8_custom, sizeof(SaIirLaneTab8)));
-    SA_HIPC(hipMalloc(&h->d_twT8, sizeof(float4) * 4 * SA8_NTHREADS));
-#endif
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint2) * SA_NPTS));
 
@@ -935,30 +824,6 @@ int sa_create(int device, sa_handle **out)
                 tc[blk * 5 + e] = make_float2((float)std::cos(ang), (float)std::sin(ang));
             }
         SA_HIPC(hipMemcpy(h->d_twT, ta.data(), sizeof(float4) * ta.size(), hipMemcpyHostToDevice));
-#ifdef SA_WITH_W8
-        // per-thread anchors of the 512-thread kernels (SaF32Tables::twT8); multiples of a quarter turn are exact
-        std::vector<float4> t8(4 * SA8_NTHREADS);
-        auto wexact = [](long e, long n) {                  // exp(-2 pi i e / n), e reduced first
-            e %= n;
-            if ((4 * e) % n == 0) {
-                const float2 q[4] = {{1.f, 0.f}, {0.f, -1.f}, {-1.f, 0.f}, {0.f, 1.f}};
-                return q[(4 * e) / n];
-            }
-            const double a = -2.0 * M_PI * (double)e / (double)n;
-            return make_float2((float)std::cos(a), (float)std::sin(a));
-        };
-        for (int t = 0; t < SA8_NTHREADS; ++t) {
-            const long u = t >> 1, g = t >> 1, half = t & 1;
-            const long k[6] = {1, 2, 3, 4, 8, 12};
-            for (int i = 0; i < 3; ++i) {
-                const float2 a = wexact(k[2 * i] * u, 4096), b = wexact(k[2 * i + 1] * u, 4096);
-                t8[i * SA8_NTHREADS + t] = make_float4(a.x, a.y, b.x, b.y);
-            }
-            const float2 a = wexact(4 * g + 4096 * half, 16384), b = wexact(4 * ((g + 1) & 255) + 4096 * half, 16384);
-            t8[3 * SA8_NTHREADS + t] = make_float4(a.x, a.y, b.x, b.y);
-        }
-        SA_HIPC(hipMemcpy(h->d_twT8, t8.data(), sizeof(float4) * t8.size(), hipMemcpyHostToDevice));
-#endif
         SA_HIPC(hipMemcpy(h->d_twB, tb.data(), sizeof(float4) * tb.size(), hipMemcpyHostToDevice));
         SA_HIPC(hipMemcpy(h->d_twC, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
@@ -968,19 +833,11 @@ int sa_create(int device, sa_handle **out)
         sos_from_q7(kDefaultQ7, sos);
         build_plan(sos, 6, &h->plan_default, &h->lt_default, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_default, &h->lt_default, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
-#ifdef SA_WITH_W8
-        build_plan8(sos, 6, &h->plan8_default, &h->lt8_default, h->half_win.data(), h->win_cos);
-        SA_HIPC(hipMemcpy(h->d_lt8_default, &h->lt8_default, sizeof(SaIirLaneTab8), hipMemcpyHostToDevice));
-#endif
         sos_from_q7(h->c12_custom, sos);
         std::memcpy(h->sos_custom, sos, sizeof sos);
         h->nsec_custom = 6;
         build_plan(sos, 6, &h->plan_custom, &h->lt_custom, h->half_win.data(), h->win_cos);
         SA_HIPC(hipMemcpy(h->d_lt_custom, &h->lt_custom, sizeof(SaIirLaneTab), hipMemcpyHostToDevice));
-#ifdef SA_WITH_W8
-        build_plan8(sos, 6, &h->plan8_custom, &h->lt8_custom, h->half_win.data(), h->win_cos);
-        SA_HIPC(hipMemcpy(h->d_lt8_custom, &h->lt8_custom, sizeof(SaIirLaneTab8), hipMemcpyHostToDevice));
-#endif
     }
     // integer tables
     {
@@ -1043,9 +900,6 @@ int sa_destroy(sa_handle *h)
     (void)hipFree(h->d_twC);
     (void)hipFree(h->d_lt_default);
     (void)hipFree(h->d_lt_custom);
-    (void)hipFree(h->d_lt8_default);
-    (void)hipFree(h->d_lt8_custom);
-    (void)hipFree(h->d_twT8);
     (void)hipFree(h->d_rom);
     (void)hipFree(h->d_twq);
     for (int i = 0; i < sa_handle::kMaxOverlap; ++i) (void)hipFree(h->d_work[i]);
@@ -1404,11 +1258,7 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     // two launches in flight take the cascade with 128-sample tiles: a second cascade then fits a CU's LDS beside the first
     // one and an FFT workgroup (measured: 10.0 vs 9.3 M frames/s at depth 2; at depth 3 the 256-sample tiles are ahead,
     // 9.6 vs 9.3, and stream-ordered by 4 %: tools/q15_overlap_depth.py)
-#ifdef SA_AB_Q15_NO_T128               // A/B builds only: always the 256-sample tiles
-    const bool small_tiles = false;
-#else
     const bool small_tiles = c.overlapped && h->overlap == 2;
-#endif
     SA_HIP(h, small_tiles
                   ? sa_launch_filter_q15_t128(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr})
                   : sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr}));
@@ -1430,8 +1280,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
     { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     // The section coefficients and predictor taps travel by value in the kernel arguments (stream-ordered
     // by construction); the per-lane matrices and the window live in device memory (stream-ordered uploads).
-    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr,
-                     h->d_twT8, h->d_lt8_custom, nullptr};
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;
@@ -1439,18 +1288,7 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
     }
-    hipError_t le = hipErrorNotSupported;
-#ifdef SA_WITH_W8                          // A/B builds only: the 512-thread probe kernels for the IIR modes with a spectrum output
-    if (h->filter_mode == SA_FILTER_DEFAULT) {
-        t.lanetab8 = h->d_lt8_default;
-        t.iir8 = &h->plan8_default;
-    } else if (h->filter_mode == SA_FILTER_CUSTOM) {
-        t.iir8 = &h->plan8_custom;
-    }
-    le = sa_launch_chain_f32_w8(in, out, batch, out_kind, t, c.stream, {c.start, c.stop});
-#endif
-    if (le == hipErrorNotSupported) le = sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, {c.start, c.stop});
-    SA_HIP(h, le);
+    SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, {c.start, c.stop}));
     return end_call(h, c);
 }
 
@@ -1467,8 +1305,7 @@ int sa_process_f32_i16(sa_handle *h, const int16_t *in, float scale, void *out, 
     SA_HIP(h, hipSetDevice(h->device));
     CallCtx c;
     { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
-    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr,
-                     h->d_twT8, h->d_lt8_custom, nullptr};
+    SaF32Tables t = {h->d_win_b, h->d_win_t, h->d_twT, h->d_twB, h->d_twC, h->d_lt_custom, nullptr};
     if (h->filter_mode == SA_FILTER_DEFAULT) {
         t.lanetab = h->d_lt_default;
         t.iir = &h->plan_default;

@@ -51,19 +51,33 @@ def random_sos(rng):
     return sos[:6], f"{kind}/{ft}/{order}"
 
 
-def sweep(ch, seed, ncases, verbose=False):
-    """Returns a list of (err, output/input peak ratio, sequential-float32 time-series err, label), one per
-    case: err = max-norm relative error of the magnitude spectrum against the float64 oracle."""
+def cases(seed, ncases):
+    """The sweep's cases, reproducible without a GPU: (index, sos, label, x [3, N] float32)."""
     rng = np.random.default_rng(seed)
+    n = np.arange(N)
+    for case in range(ncases):
+        sos, label = random_sos(rng)
+        x = (rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.001, 0.49, (3, 1)) * n)
+             + rng.uniform(0.0, 0.2) * rng.standard_normal((3, N))).astype(np.float32)
+        yield case, sos, label, x
+
+
+def sweep(ch, seed, ncases, verbose=False, only=None):
+    """Returns a list of (err, output/input peak ratio, sequential-float32 err, label), one per case (`only`: a set of
+    case indices to evaluate; the others are drawn and skipped).  Both errors are
+    in ONE norm: the max-norm error of the MAGNITUDE SPECTRUM against the float64 oracle, relative to that spectrum's
+    peak, worst of the case's three frames -- `err` for the GPU, `sequential-float32 err` for the spectrum (float64
+    rfft) of a sequential float32 evaluation of scipy's own recurrence on the same windowed float32 input.  (Until
+    round 3 the second figure was the TIME-SERIES error relative to the time-series peak: for outputs that are
+    stop-band leakage the two norms differ by design, and the "4 x sequential" statement compared unlike things.)"""
     hann64 = orc.hann_f64()
     hann = hann64.astype(np.float32)
     ch.set_filter_mode(0xA1)
     out = []
-    for case in range(ncases):
-        sos, label = random_sos(rng)
-        n = np.arange(N)
-        x = (rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.001, 0.49, (3, 1)) * n)
-             + rng.uniform(0.0, 0.2) * rng.standard_normal((3, N))).astype(np.float32)
+    for case, sos, label, x in cases(seed, ncases):
+        if only is not None and case not in only:           # named regression cases: the draws are made, the work is not
+            continue
+        label = f"{label} [seed {seed} case {case}]"
         y64, X, mag = orc.chain_fp(x, sos)
         ch.load_sos(sos)
         got = ch.process_f32(torch.from_numpy(x).cuda()).cpu().numpy()
@@ -73,13 +87,14 @@ def sweep(ch, seed, ncases, verbose=False):
         # what a sequential float32 sosfilt achieves on the same input, and how far below the windowed input
         # the output sits: rounding scales with the input, the norm with the output
         seq = np.stack([orc.sosfilt_f32_c(sos / sos[:, 3:4], r) for r in (x * hann).astype(np.float32)])
-        seq_err = float(np.abs(seq - y64).max() / max(np.abs(y64).max(), 1e-30))
+        seq_mag = np.abs(np.fft.rfft(seq.astype(np.float64), axis=1))
+        seq_err = float((np.abs(seq_mag - mag[:, :N // 2 + 1]).max(axis=1) / np.where(den > 0, den, 1.0)).max())
         xin = np.abs(np.fft.rfft(x.astype(np.float64) * hann64, axis=1)).max(axis=1)
         att = float((den / xin).min())
         out.append((err, att, seq_err, label))
         if verbose and err > max(1e-5, 4 * seq_err):
             print(f"case {case} {label} nsec={len(sos)}: err {err:.2e} output/input peak {att:.1e} "
-                  f"(sequential f32 time-series err {seq_err:.2e})")
+                  f"(sequential f32 spectrum err {seq_err:.2e})")
     return out
 
 
@@ -89,9 +104,13 @@ def main():
     res = sweep(SpectrumChain(0), seed, ncases, verbose=True)
     over = [r for r in res if r[0] > 1e-5]
     bad = [r for r in over if r[0] > 4 * r[2]]
-    print(f"{ncases} cases, worst spectrum err {max(r[0] for r in res):.2e}, {len(over)} above 1e-5, "
-          f"{len(bad)} above max(1e-5, 4 x sequential-f32); of those above 1e-5 the largest output/input peak "
-          f"ratio is {max([r[1] for r in over], default=0):.1e}")
+    bad2 = [r for r in over if r[0] > 2 * r[2]]
+    seq_over = [r for r in res if r[2] > 1e-5]
+    print(f"{ncases} cases, worst spectrum err {max(r[0] for r in res):.2e}, {len(over)} above 1e-5 "
+          f"(a sequential float32 evaluation: {len(seq_over)} above 1e-5), {len(bad)} above max(1e-5, 4 x sequential-f32), "
+          f"{len(bad2)} above max(1e-5, 2 x sequential-f32), worst ratio "
+          f"{max([r[0] / max(r[2], 1e-30) for r in over], default=0):.1f}; of those above 1e-5 the largest output/input "
+          f"peak ratio is {max([r[1] for r in over], default=0):.1e}")
     for err, att, seq_err, label in sorted(over, reverse=True)[:12]:
         print(f"   err {err:.2e}  output/input peak {att:.1e}  sequential-f32 {seq_err:.2e}  {label}")
 

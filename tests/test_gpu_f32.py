@@ -94,9 +94,11 @@ def test_g3_golden_frames(ch, torch_mod):
     assert rel_maxnorm(y, g["y_full"]) <= TOL
 
 
-@pytest.mark.parametrize("B", [1, 3, 64, 256])
+@pytest.mark.parametrize("B", [1, 3, 64, 256, 512, 513])
 def test_bypass_vs_oracle(ch, torch_mod, oracle, B):
-    """BASELINE config 2 (B=256) and ragged batches, IIR bypassed."""
+    """BASELINE config 2 (B=256) and ragged batches, IIR bypassed.  Batches up to 512 frames take the one-round
+    stage-in (a whole frame in a 64 KiB LDS image, two workgroups per CU), larger ones the two half-frame rounds:
+    512 and 513 sit on either side of the switch, and the two forms must agree bit for bit on the same frames."""
     x = synth(B, seed=B)
     _, X, mag = oracle.chain_fp(x, None)
     xd = _dev(torch_mod, x)
@@ -106,6 +108,11 @@ def test_bypass_vs_oracle(ch, torch_mod, oracle, B):
     assert rel_maxnorm(np.abs(spec - X), np.abs(X)) <= 1.0 and np.abs(spec - X).max(axis=1).max() <= TOL * np.abs(X).max()
     y = ch.process_f32(xd, out_kind="time").cpu().numpy()
     assert rel_maxnorm(y, x.astype(np.float64) * oracle.hann_f64()) <= 1e-6
+    if B == 513:                                    # the first 512 frames again, now through the small-batch form
+        for kind in ("mag_full", "mag_half", "spec_half"):
+            big = ch.process_f32(xd, out_kind=kind)
+            small = ch.process_f32(xd[:512].contiguous(), out_kind=kind)
+            assert torch_mod.equal(big[:512], small), kind
 
 
 @pytest.mark.parametrize("B", [1, 5, 128])
@@ -164,15 +171,23 @@ def test_long_memory_filter_uses_every_scan_level(ch, torch_mod, oracle):
 
 def test_random_designs(ch, torch_mod):
     """160 random cascades (five scipy families, all four band types, orders 1..12, hand-made sections with
-    zero / unit / negative numerators) x random tones + noise.  The accuracy statement of DESIGN.md section 2:
-    the spectrum is within 1e-5 (max-norm, relative to its own peak) of the float64 oracle, or -- when the
-    filter removes the dominant input or has poles so close to the unit circle that float32 itself runs out
-    -- within 4x of what a *sequential* float32 sosfilt achieves on the same data.  (A tighter factor is not a
-    property any float32 recursion has: with EXACT chunk start states the same spread remains, 10 of 4500 designs
-    above 1.5x -- tools/accuracy_study.py, profiles/r2_accuracy_study.txt.)"""
+    zero / unit / negative numerators) x random tones + noise.  The accuracy statement of include/specan.h, in one
+    norm (spectrum error relative to the spectrum peak, for the GPU and for the sequential float32 evaluation alike):
+    within 1e-5 of the float64 oracle, or -- when the filter removes the dominant input or has poles so close to the
+    unit circle that float32 itself runs out -- within 4x of what a *sequential* float32 sosfilt achieves on the same
+    data.  Over 4500 designs (seeds 7 / 11 / 23, profiles/r4_fuzz.txt) two exceed that factor; they and a third outlier
+    are pinned here by name with the bounds they meet, so that a change of the cascade's algebra that moves them shows."""
     from fuzz_parity import sweep
     for err, att, seq_err, label in sweep(ch, seed=7, ncases=160):
         assert err <= max(TOL, 4 * seq_err), (label, err, att, seq_err)
+    # named outliers: (seed, case) -> bound on the spectrum error; measured 8.2e-5 (4.0x sequential), 4.0e-5 (3.4x), 2.4e-4 (15.6x)
+    pinned = {7: {752: 1.2e-4, 1203: 6e-5}, 11: {929: 3.5e-4}}
+    for seed, want in pinned.items():
+        got = sweep(ch, seed=seed, ncases=max(want) + 1, only=set(want))
+        assert len(got) == len(want)
+        for (err, att, seq_err, label), case in zip(got, sorted(want)):
+            assert f"case {case}]" in label
+            assert TOL < err <= want[case], (label, err, seq_err)      # still an outlier, still within its bound
 
 
 def test_default_mode_is_the_rtl_taps_as_reals(ch, torch_mod, oracle):

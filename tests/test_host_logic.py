@@ -109,8 +109,7 @@ def test_udp_packetiser_roundtrip():
     assert got == frame and asm.frames == 1
     assert asm.add(b"\x40" + bytes(1024), 0) is None          # index out of range ignored
     assert asm.add(bytes(10), 0) is None                      # wrong length ignored
-    asm.add(pk[0], 0)
-    asm.add(pk[1], 5000)                                      # evicts the stale slot 0
+    assert asm.add(pk[0], 0) is None and asm.frames == 1      # a partial frame stays pending (the collector has no time-out)
 
 
 def test_pack_frame_is_little_endian(hip_lib_built):
@@ -314,13 +313,3 @@ def test_fft_regs_host(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fft32" in r.stdout
-
-
-def test_w8_probe_index_model():
-    """The index model of the parked 512-thread kernel (csrc/probes/chain_f32_w8.hip): every exchange, twiddle and the
-    merged radix-2 / split output stage with the kernel's own index formulas, against numpy.fft (tools/w8_model.py)."""
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "w8_model.py")], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "w8 index model vs numpy.fft" in r.stdout

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Collect the round's judged profile artefacts on the GPU box (run through gpurun); outputs under
 # gpurun_out/round_profiles/, to be copied into profiles/ by the caller.  usage: collect_profiles.sh TAG
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/round_profiles; rm -rf $OUT; mkdir -p $OUT
-# 1. kernel-trace stats of the bench command itself: headline mode (two launches in flight) and the strictly
-#    stream-ordered mode (the judged average duration of the dominant kernel is the ordered one: overlapped kernels
-#    share the chip and last longer each)
+# 1. kernel-trace stats of the bench command itself, in two SEPARATE processes so that no kernel's average mixes modes:
+#    `--overlap 1 --extras` launches every kernel of the product strictly stream-ordered (float chain, bypass, both
+#    integer cascades, the wide cascade, the integer FFT) -> ${TAG}_kernel_stats.csv, the judged per-kernel durations;
+#    the default line (two launches in flight) with its extras -> ${TAG}_kernel_stats_overlap2.csv (overlapped kernels
+#    share the chip and last longer each).  --no-power: no side thread, no child process under the profiler.
 stats() {   # stats TRACE_DIR OUT_CSV
 python3 - "$1" "$2" <<'PY'
 import csv, glob, sys
@@ -14,7 +16,7 @@ src, dst = sys.argv[1], sys.argv[2]
 rows = []
 for f in glob.glob(src + "/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-keep = [r for r in rows if "chain_f32" in r["Name"] or "q15" in r["Name"] or "q7" in r["Name"]]
+keep = [r for r in rows if any(k in r["Name"] for k in ("chain_f32", "q15", "q7", "w14"))]
 with open(dst, "w") as fh:
     w = csv.writer(fh)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
@@ -23,9 +25,9 @@ with open(dst, "w") as fh:
         w.writerow([nm.split("(")[0] + (" [int16 samples in]" if "(short const*" in nm and "_f32_kernel" in nm else ""), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 PY
 }
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 bench.py --overlap 1 --no-cpu-baseline --extras --steps 20 > $OUT/${TAG}_bench_ordered_under_rocprof.json 2> $OUT/bench_ordered_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 bench.py --overlap 1 --no-cpu-baseline --no-power --extras --steps 20 > $OUT/${TAG}_bench_ordered_under_rocprof.json 2> $OUT/bench_ordered_under_rocprof.err
 stats $OUT/trace1 $OUT/${TAG}_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 bench.py --no-cpu-baseline --steps 20 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 bench.py --no-cpu-baseline --no-power --extras --steps 20 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 stats $OUT/trace2 $OUT/${TAG}_kernel_stats_overlap2.csv
 # 2. un-profiled bench lines (with the CPU baseline): headline mode with the extras, ordered mode
 python3 bench.py --extras > $OUT/${TAG}_bench.json 2> $OUT/bench.err
@@ -34,6 +36,7 @@ python3 bench.py --overlap 1 --no-cpu-baseline > $OUT/${TAG}_bench_ordered.json 
 bash tools/pmc_profile.sh 0xA1 round_profiles/pmc_iir > $OUT/${TAG}_pmc_chain_f32_iir.txt 2>&1
 bash tools/pmc_profile.sh 0xB1 round_profiles/pmc_byp > $OUT/${TAG}_pmc_chain_f32_noiir.txt 2>&1
 bash tools/pmc_profile.sh q15 round_profiles/pmc_q15 > $OUT/${TAG}_pmc_q15.txt 2>&1
+SA_PMC_SHORT=1 bash tools/pmc_profile.sh q15wide round_profiles/pmc_q15wide > $OUT/${TAG}_pmc_q15_wide.txt 2>&1
 SA_PMC_SHORT=1 bash tools/pmc_profile.sh 0xA1 round_profiles/pmc_spec spec_half > $OUT/${TAG}_pmc_chain_f32_spec_half.txt 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 # HBM traffic per launch of the headline kernel for bench.py's roofline.traffic (FETCH_SIZE doubled: gfx950 counts the
@@ -69,5 +72,5 @@ python3 tools/wg_timeline.py 4096 0xA1 > $OUT/${TAG}_wg_timeline.txt 2>&1
 python3 tools/ingest_bench.py 1024 32 0xB1 --events > $OUT/${TAG}_ingest_raw.txt 2>&1
 # 6. package power and shader clock while the chain runs (the launch is power-limited: profiles/r3_power_clock.txt)
 python3 tools/power_clock.py 4 > $OUT/${TAG}_power_clock_raw.txt 2>&1
-rm -rf $OUT/trace1 $OUT/trace2 $OUT/pmc_iir $OUT/pmc_byp $OUT/pmc_q15 $OUT/pmc_spec
+rm -rf $OUT/trace1 $OUT/trace2 $OUT/pmc_iir $OUT/pmc_byp $OUT/pmc_q15 $OUT/pmc_q15wide $OUT/pmc_spec
 ls -la $OUT

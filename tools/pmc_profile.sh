@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes for the fused float kernel, or the Q15 kernels with MODE = q15 (run on the GPU box through gpurun).
+# PMC passes for the fused float kernel, or the Q15 kernels with MODE = q15 (default cascade) / q15wide (0xA2) (run on the GPU box through gpurun).
 # usage: pmc_profile.sh MODE TAG [OUT_KIND]   (SA_PMC_SHORT=1: the SQ and traffic passes only)
 # Counters go in separate passes (SQ 8 slots, TCC 4: FETCH_SIZE takes 3, WRITE_SIZE 2).
 MODE=${1:-0xA1}; TAG=${2:-pmc}; KIND=${3:-mag_full}

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if "chain_f32" not in k and "q15" not in k and "q7" not in k:
+            if not any(t in k for t in ("chain_f32", "q15", "q7", "w14")):
                 continue
             name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))

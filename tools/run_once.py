@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tiny driver for profilers: run the fused float chain a few times.  usage: run_once.py MODE B ITERS [OUT_KIND]"""
+"""Tiny driver for profilers: run the fused float chain a few times.  usage: run_once.py MODE B ITERS [OUT_KIND]   (MODE: a filter byte for the float chain, or q15 / q15wide)"""
 import os
 import sys
 
@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
 
-q15 = len(sys.argv) > 1 and sys.argv[1] == "q15"
+q15 = len(sys.argv) > 1 and sys.argv[1] in ("q15", "q15wide")
+wide = len(sys.argv) > 1 and sys.argv[1] == "q15wide"
 mode = 0x00 if q15 else (int(sys.argv[1], 0) if len(sys.argv) > 1 else 0xA1)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
@@ -20,7 +21,9 @@ if q15:                                           # config 4: integer cascade + 
     xq = torch.randint(-2048, 2048, (B, 16384), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
     oq = torch.empty((B, 16384, 2), dtype=torch.int16, device="cuda")
     ch.reserve(B)
-    ch.set_filter_mode(0x00)
+    if wide:                                       # mode 0xA2: the Q2.14 quantisation of the 12th-order Butterworth (fixture G4)
+        ch.load_sos_q14(np.load(os.path.join(ROOT, "tests", "golden", "g4_q15_frames.npz"))["sos_q14"])
+    ch.set_filter_mode(0xA2 if wide else 0x00)
     for _ in range(iters):
         ch.process_q15(xq, out=oq)
     torch.cuda.synchronize()
