@@ -625,6 +625,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     SA_Q15_STAMP_END();
 }
 
+#ifndef SA_Q15_SECOND_TU     // the wide cascade exists with the large tiles only (overlap mode does not pay for it: specan_abi.cpp)
 // ------------------------------------------------------------------------------------------ IIR, wide Q2.14 form
 // Mode 0xA2 (the build's own spec, oracle/specan_oracle.c:or_iir_sos_q14; the six sections scripts/fft_analyzer_gui.py:108-157
 // designs and :1186-1192 cuts down to two): per section, direct form I,
@@ -785,6 +786,8 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
     }
     SA_Q15_STAMP_END();
 }
+
+#endif  // !SA_Q15_SECOND_TU
 
 // ------------------------------------------------------------------------------------------ FFT
 
@@ -1037,7 +1040,11 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
         hipExtLaunchKernelGGL(window_q15_kernel, dim3((batch + kFramesPerWave - 1) / kFramesPerWave), dim3(64), 0, stream, ev.start,
                               ev.stop, 0, in, out_time, batch, p, t.rom);
     } else if (p.filter == SA_FILTER_WIDE) {
+#ifdef SA_Q15_SECOND_TU
+        return hipErrorInvalidValue;           // not built with the small tiles
+#else
         hipExtLaunchKernelGGL(filter_w14_kernel, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
+#endif
     } else {
         // B1 = 0 in both coefficient sets (wire order b0,b1,b2,a0,a1,a2 per set): the seven-instruction step
         const bool nob1 = p.c12[1] == 0 && p.c12[7] == 0;

@@ -163,7 +163,7 @@ def test_overlapped_launches_q15(ch, torch_mod, oracle):
             if k == 3:                                       # control plane between overlapped calls: custom coefficients
                 ch.load_coeffs_q7(gui)
                 ch.set_filter_mode(0xA1)
-            if k == 5:                                       # ... and the wide cascade (its 128-sample-tile build)
+            if k == 5:                                       # ... and the wide cascade (ordered behind the previous call)
                 ch.load_sos_q14(wide)
                 ch.set_filter_mode(0xA2)
             outs.append(ch.process_q15(x))

@@ -66,11 +66,12 @@ PY
 python3 tools/phase_stamps.py 4096 0xA1 > $OUT/${TAG}_phase_stamps_iir.txt 2>&1
 python3 tools/phase_stamps.py 256 0xA1 > $OUT/${TAG}_phase_stamps_iir_lone.txt 2>&1
 python3 tools/phase_stamps.py 4096 0xB1 > $OUT/${TAG}_phase_stamps_noiir.txt 2>&1
+python3 tools/phase_stamps.py 256 0xB1 > $OUT/${TAG}_phase_stamps_noiir_lone.txt 2>&1
 python3 tools/wg_timeline.py 4096 0xA1 > $OUT/${TAG}_wg_timeline.txt 2>&1
 # 5. memory skeleton and ingest
 ./tools/ubench/frame_stream 4096 6 60 > $OUT/${TAG}_memory_skeleton_raw.txt 2>&1
 python3 tools/ingest_bench.py 1024 32 0xB1 --events > $OUT/${TAG}_ingest_raw.txt 2>&1
-# 6. package power and shader clock while the chain runs (the launch is power-limited: profiles/r3_power_clock.txt)
-python3 tools/power_clock.py 4 > $OUT/${TAG}_power_clock_raw.txt 2>&1
+# (package power and shader clock: bench.py samples them in process from sysfs next to the headline -- roofline.power in
+#  ${TAG}_bench.json; the round-3 study is profiles/r3_power_clock.txt, tools/power_clock.py)
 rm -rf $OUT/trace1 $OUT/trace2 $OUT/pmc_iir $OUT/pmc_byp $OUT/pmc_q15 $OUT/pmc_q15wide $OUT/pmc_spec
 ls -la $OUT

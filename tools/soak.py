@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run on the GPU box (test infrastructure: uses the oracle): random batch sizes, filter modes, coefficient
 uploads, window modes and input scales through the Q15 path, bit-exact against the integer model every time;
-float chain on random batch sizes (float32 frames or int16 samples in) within tolerance.  Round 3: the launch mode changes at random (ordered, two or three
+float chain on random batch sizes (float32 frames or int16 samples in) within tolerance.  Round 4: mode 0xA2 (random wide cascades) is in the mix.  Round 3: the launch mode changes at random (ordered, two or three
 launches in flight: sa_set_overlap), in overlap mode up to three calls are issued back to back before the flush, with control-plane
 calls between them.  usage: soak.py SECONDS [SEED] [big]"""
 import os
@@ -41,8 +41,14 @@ while time.time() - t0 < budget:
         B = int(rng.choice(BATCHES))
         scale = int(rng.choice([16, 2048, 32768]))
         x = rng.integers(-scale, scale, size=(B, N)).astype(np.int16)
-        cmd = int(rng.choice([0x00, 0xA1, 0xB1]))
+        cmd = int(rng.choice([0x00, 0xA1, 0xB1, 0xA2]))
         wm = int(rng.integers(0, 2))
+        sos14 = None
+        if cmd == 0xA2:                                     # round 4: random wide cascades, 1..6 sections, any int16 tap
+            sos14 = rng.integers(-32768, 32768, (int(rng.integers(1, 7)), 6)).astype(np.int16)
+            if rng.integers(0, 2):
+                sos14 = (sos14 // 4).astype(np.int16)
+            ch.load_sos_q14(sos14)
         c12 = rng.integers(-128, 128, size=12).astype(np.int8)
         if rng.integers(0, 3) == 0:
             c12[1] = c12[7] = 0                             # the short integer step
@@ -50,7 +56,7 @@ while time.time() - t0 < budget:
         if cmd == 0xA1:
             ch.load_coeffs_q7(c12)
         ch.set_filter_mode(cmd)
-        ref = orc.chain_q15(x, None, wm, cmd, c12 if cmd == 0xA1 else None, None)
+        ref = orc.chain_q15(x, None, wm, cmd, c12 if cmd == 0xA1 else None, sos14)
         xd = torch.from_numpy(x).cuda()                     # kept until the flush: in overlap mode the tensors of a call
         pending.append((ch.process_q15(xd), ref, B, cmd, wm, scale, xd))     # belong to the library until it is joined
     if depth > 1:
@@ -67,7 +73,7 @@ while time.time() - t0 < budget:
         xf = (rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.001, 0.2, (Bf, 1)) * np.arange(N))
               + 0.05 * rng.standard_normal((Bf, N))).astype(np.float32)
         ch.load_sos(sos)
-        ch.set_filter_mode(0xA1 if rng.integers(0, 2) else 0xB1)
+        ch.set_filter_mode(0xA1 if rng.integers(0, 2) else 0xB1)       # (bypassed batches <= 512 take the one-round stage-in)
         _, _, mag = orc.chain_fp(xf, sos if ch.filter_mode == 0xA1 else None)
         if rng.integers(0, 2):                              # the same chain from int16 samples (sa_process_f32_i16)
             xi = np.clip(np.round(xf * 2048.0), -32768, 32767).astype(np.int16)
