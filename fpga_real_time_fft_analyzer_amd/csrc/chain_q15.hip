@@ -382,8 +382,10 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
     "ds_read_u16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
     SA_Q7_TBLOCK("v52", "v59") SA_Q7_TBLOCK("v53", "v52") SA_Q7_TBLOCK("v54", "v53") SA_Q7_TBLOCK("v55", "v54")        \
     SA_Q7_TBLOCK("v56", "v55") SA_Q7_TBLOCK("v57", "v56") SA_Q7_TBLOCK("v58", "v57") SA_Q7_TBLOCK("v59", "v58")        \
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
     "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF0 "\n\t"                                                             \
-    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"
+    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"                                                             \
+    "s_mov_b64 exec, %[sv]\n\t"
 
 // The same block when the port tap B1 is zero in BOTH coefficient sets (the fixed ALPHA / BETA cascade of mode 0x00,
 // imp/filter_pkg.vhd:54-68; the identity stages have B1 = 0 anyway): t(0, v) = 0 exactly, so the product D and the add G
@@ -460,15 +462,18 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
     "ds_read_u16 %[xin], %[xa] offset:" RD_OFF "\n\t"                                                                  \
     SA_Q7_NB1BLOCK("v52", "v59") SA_Q7_NB1BLOCK("v53", "v52") SA_Q7_NB1BLOCK("v54", "v53") SA_Q7_NB1BLOCK("v55", "v54")  \
     SA_Q7_NB1BLOCK("v56", "v55") SA_Q7_NB1BLOCK("v57", "v56") SA_Q7_NB1BLOCK("v58", "v57") SA_Q7_NB1BLOCK("v59", "v58")  \
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
     "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF0 "\n\t"                                                             \
-    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"
+    "ds_write_b128 %[ra], v[56:59] offset:" WR_OFF1 "\n\t"                                                             \
+    "s_mov_b64 exec, %[sv]\n\t"
 
 // xa: LDS byte address of the lane's refill slot of the tile's first group; ra: of the ring slot of its outputs
 template <bool NOB1>
-__device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, unsigned ra, unsigned rinc, unsigned long long in_mask,
-                                        int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
+__device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, unsigned ra, unsigned long long in_mask,
+                                        unsigned long long out_mask, int cB2, int cB1, int cB0, int nA0, int nA1, int k127)
 {
     int xin, cnt = kTile / 32;
+    unsigned long long saved;
     if constexpr (NOB1) {
         // the seven-instruction block: p1 and u are not touched (p1 stays the zero it is: the drain group's block reads it)
         asm volatile(
@@ -480,7 +485,7 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
             "1:\n\t"
             SA_Q7_NB1GROUP("16", "0", "16") SA_Q7_NB1GROUP("32", "32", "48") SA_Q7_NB1GROUP("48", "64", "80") SA_Q7_NB1GROUP("64", "96", "112")
             "v_add_u32 %[xa], 64, %[xa]\n\t"
-            "v_add_u32 %[ra], %[rinc], %[ra]\n\t"
+            "v_add_u32 %[ra], 0x80, %[ra]\n\t"
             "s_add_i32 %[cnt], %[cnt], -1\n\t"
             "s_cmp_lg_u32 %[cnt], 0\n\t"
             "s_cbranch_scc1 1b\n\t"
@@ -489,8 +494,8 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
             "v_mov_b32 %[y4], v56\n\tv_mov_b32 %[y5], v57\n\tv_mov_b32 %[y6], v58\n\tv_mov_b32 %[y7], v59"
             : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]),
               [y7] "+v"(y[7]), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p2] "+v"(c.p2), [p3] "+v"(c.p3), [p4] "+v"(c.p4),
-              [t] "+v"(c.t), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt)
-            : [cB2] "v"(cB2), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask), [rinc] "v"(rinc)
+              [t] "+v"(c.t), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt), [sv] "=&s"(saved)
+            : [cB2] "v"(cB2), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask), [outm] "s"(out_mask)
             : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
         // hand-over to the nine-instruction block of the drain group: its G adds hi(p1) = 0 and hi(p2) of the last B
         // into u BEFORE its I -- consistent with what the last I of this loop left in s2 only if u is rebuilt the same way,
@@ -506,7 +511,7 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
         "1:\n\t"
         SA_Q7_TGROUP("16", "0", "16") SA_Q7_TGROUP("32", "32", "48") SA_Q7_TGROUP("48", "64", "80") SA_Q7_TGROUP("64", "96", "112")
         "v_add_u32 %[xa], 64, %[xa]\n\t"
-        "v_add_u32 %[ra], %[rinc], %[ra]\n\t"
+        "v_add_u32 %[ra], 0x80, %[ra]\n\t"
         "s_add_i32 %[cnt], %[cnt], -1\n\t"
         "s_cmp_lg_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
@@ -515,9 +520,9 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
         "v_mov_b32 %[y4], v56\n\tv_mov_b32 %[y5], v57\n\tv_mov_b32 %[y6], v58\n\tv_mov_b32 %[y7], v59"
         : [y0] "+v"(y[0]), [y1] "+v"(y[1]), [y2] "+v"(y[2]), [y3] "+v"(y[3]), [y4] "+v"(y[4]), [y5] "+v"(y[5]), [y6] "+v"(y[6]),
           [y7] "+v"(y[7]), [s2] "+v"(c.s2), [p0] "+v"(c.p0), [p1] "+v"(c.p1), [p2] "+v"(c.p2), [p3] "+v"(c.p3), [p4] "+v"(c.p4),
-          [t] "+v"(c.t), [u] "+v"(c.u), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt)
+          [t] "+v"(c.t), [u] "+v"(c.u), [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [cnt] "+s"(cnt), [sv] "=&s"(saved)
         : [cB2] "v"(cB2), [cB1] "v"(cB1), [cB0] "v"(cB0), [nA0] "v"(nA0), [nA1] "v"(nA1), [k] "s"(k127), [inm] "s"(in_mask),
-          [rinc] "v"(rinc)
+          [outm] "s"(out_mask)
         : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
 }
 
@@ -575,12 +580,10 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     // are identity stages, s2 = 0) at the start of a group
     const int kin = (16 - l16) & 15;                       // 0..7 for the input lanes
     const bool is_in = kin < 8;
-    const unsigned long long out_mask = kOutMask;                  // lane 8 of every row that carries a frame (drain group)
-    const bool is_out = l16 == 8;
+    const unsigned long long out_mask = kOutMask;                  // lane 8 of every row that carries a frame
     const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
     const uint16_t *xrow = reinterpret_cast<const uint16_t *>(&tin[fr][0]) + (is_in ? kin : 0);
     const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const uint16_t *)xrow;
-    const unsigned tin_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int16_t *)(&tin[fr][0]);
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)(&ring[fr][0]);
 
     int y[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // the lane's last eight outputs
@@ -614,11 +617,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         // group of a tile requests the slots after its half of the ring (the other half, or the row's 8-element
         // pad): a valid address whose value is not used.
         const int i0 = (k & 1) * kTile;
-        // store addresses of the tile: lane 8 of a row writes the output ring and advances 32 dwords per loop pass; every other
-        // lane scribbles into the half of its row's INPUT ring that holds no live data during this tile (256 bytes from its start
-        // cover the four groups of a pass for all of them: 16-byte slots, lanes l and l + 8 share one) and does not advance
-        const unsigned ra = is_out ? ring_addr + 4 * i0 : tin_addr + 2 * (kTile - i0) + 16 * (l16 & 7);
-        if (live) q7_tile<NOB1>(y, c, xrow_addr + 2 * i0, ra, is_out ? 0x80u : 0u, in_mask, cB2, cB1, cB0, nA0, nA1, k127);
+        if (live) q7_tile<NOB1>(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
         else group(k * kTile, xrow[i0]);
         wave_lds_sync();
         if (k >= 1) q7_flush_tile(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane);
@@ -704,14 +703,17 @@ struct W14Carry {
     SA_W14_BLOCK("v58", "v54", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
     SA_W14_BLOCK("v54", "v59", "%[x0]", "%[x1]", "%[w0]", "%[w1]", "")                                                 \
     SA_W14_BLOCK("v59", "v55", "%[x1]", "%[x0]", "%[w1]", "%[w0]", "")                                                 \
-    "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF "\n\t"
+    "s_and_saveexec_b64 %[sv], %[outm]\n\t"                                                                            \
+    "ds_write_b128 %[ra], v[52:55] offset:" WR_OFF "\n\t"                                                              \
+    "s_mov_b64 exec, %[sv]\n\t"
 
 // `iters` x 4 groups x 8 steps.  xa: LDS byte address of the lane's refill slot of the first group; ra: of the ring slot
 // of its outputs.  The refill is requested one group ahead (lgkmcnt(1): everything but the store behind it).
-__device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned xa, unsigned ra, unsigned rinc,
-                                         unsigned long long in_mask, int iters)
+__device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned xa, unsigned ra, unsigned long long in_mask,
+                                         unsigned long long out_mask, int iters)
 {
     int xin, al, ah;
+    unsigned long long saved;
     asm volatile(
         "v_mov_b32 v56, %[p0]\n\tv_mov_b32 v52, %[p1]\n\tv_mov_b32 v57, %[p2]\n\tv_mov_b32 v53, %[p3]\n\t"
         "v_mov_b32 v58, %[p4]\n\tv_mov_b32 v54, %[p5]\n\tv_mov_b32 v59, %[p6]\n\tv_mov_b32 v55, %[p7]\n\t"
@@ -721,7 +723,7 @@ __device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned
         "1:\n\t"
         SA_W14_GROUP("16", "0") SA_W14_GROUP("32", "16") SA_W14_GROUP("48", "32") SA_W14_GROUP("64", "48")
         "v_add_u32 %[xa], 64, %[xa]\n\t"
-        "v_add_u32 %[ra], %[rinc], %[ra]\n\t"
+        "v_add_u32 %[ra], 64, %[ra]\n\t"
         "s_add_i32 %[cnt], %[cnt], -1\n\t"
         "s_cmp_lg_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
@@ -730,9 +732,9 @@ __device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned
         "v_mov_b32 %[p4], v58\n\tv_mov_b32 %[p5], v54\n\tv_mov_b32 %[p6], v59\n\tv_mov_b32 %[p7], v55"
         : [p0] "+v"(c.p[0]), [p1] "+v"(c.p[1]), [p2] "+v"(c.p[2]), [p3] "+v"(c.p[3]), [p4] "+v"(c.p[4]), [p5] "+v"(c.p[5]),
           [p6] "+v"(c.p[6]), [p7] "+v"(c.p[7]), [w0] "+v"(c.w0), [w1] "+v"(c.w1), [x0] "+v"(c.x0), [x1] "+v"(c.x1),
-          [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [al] "=&v"(al), [ah] "=&v"(ah), [cnt] "+s"(iters)
+          [xa] "+v"(xa), [ra] "+v"(ra), [xin] "=&v"(xin), [al] "=&v"(al), [ah] "=&v"(ah), [cnt] "+s"(iters), [sv] "=&s"(saved)
         : [c01l] "v"(t.c01l), [c01h] "v"(t.c01h), [c2l] "v"(t.c2l), [c2h] "v"(t.c2h), [cfbl] "v"(t.cfbl), [cfbh] "v"(t.cfbh),
-          [k] "s"(8192), [inm] "s"(in_mask), [rinc] "v"(rinc)
+          [k] "s"(8192), [inm] "s"(in_mask), [outm] "s"(out_mask)
         : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
 }
 
@@ -758,11 +760,10 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
     }
     const int kin = (16 - l16) & 15;                         // 0..7 for the input lanes: lanes 0, 15, .., 9 take samples T0 .. T0+7
     const bool is_in = kin < 8;
-    const bool is_out = l16 == 8;                                 // lane 8 of every row emits
+    const unsigned long long out_mask = kOutMask;                  // lane 8 of every row that carries a frame
     const unsigned long long in_mask = 0xFE01FE01FE01FE01ull;    // lanes 0 and 9..15
     const int16_t *xrow = &tin[fr][0] + (is_in ? kin : 0);
     const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int16_t *)xrow;
-    const unsigned tin_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int16_t *)(&tin[fr][0]);
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)(&ring[fr][0]);
 
     W14Carry c = {};
@@ -778,10 +779,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
         // starts at step T0).  The drain pass runs one iteration = four groups: the first delivers the frame's last eight
         // samples, the other three filter whatever the input ring holds into slots that were flushed long ago.
         const int i0 = (k & 1) * kTile;
-        // lane 8 of a row stores into the output ring; the other lanes scribble into the dead half of the row's input ring
-        // (see filter_q7_kernel): no exec mask around the store
-        const unsigned ra = is_out ? ring_addr + 2 * i0 : tin_addr + 2 * (kTile - i0) + 16 * (l16 & 7);
-        w14_tile(c, taps, xrow_addr + 2 * i0, ra, is_out ? 64u : 0u, in_mask, live ? kTile / 32 : 1);
+        w14_tile(c, taps, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, live ? kTile / 32 : 1);
         wave_lds_sync();
         if (k >= 1)
             q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile + 8) & (kRing - 1), f0, batch, (k - 1) * kTile, lane, kRing - 1);
