@@ -345,6 +345,14 @@ class GpuWorkload:
             r["bytes_per_frame"] = BYTES_PER_FRAME_F32
             r["workload"] = "BASELINE.json configs[1]: batch=256 x 16K fp32, Hann + 16K FFT + magnitude, IIR bypassed, stream-ordered"
             out["config2_b256_bypass"] = r
+        # the same bypassed chain on the headline's batch (not a BASELINE configuration; SURVEY hypothesis H6 names the
+        # bypassed chain as the place where 0.70 of the HBM roofline is realistic first)
+        r = self._measure(self.step, B, BYTES_PER_FRAME_F32, 40, 1)
+        r["bytes_per_frame"] = BYTES_PER_FRAME_F32
+        r["workload"] = f"batch={B} x 16K fp32, Hann + 16K FFT + magnitude, IIR bypassed (the headline's buffers)"
+        if R > 2 and with_overlap:
+            r["overlap2"] = self._measure(self.step, B, BYTES_PER_FRAME_F32, 40, 2)
+        out["bypass_b4096"] = r
         ch.set_filter_mode(0xA1)
         xqs = [torch.randint(-2048, 2048, (B, N), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
                for _ in range(R)]

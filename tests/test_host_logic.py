@@ -313,3 +313,29 @@ def test_fft_regs_host(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fft32" in r.stdout
+
+
+def test_wide_step_split_accumulators_are_exact():
+    """The wide Q2.14 step of the GPU kernel (chain_q15.hip, filter_w14_kernel) never forms the 34-bit sum of
+    or_iir_sos_q14: every tap -- and every NEGATED feedback tap, which reaches +32768 -- splits as c = 2^14 ch + cl with
+    cl in [-8192, 8191], the two sums acc_l = 8192 + sum cl v and acc_h = sum ch v stay inside 32 bits at every partial sum,
+    and (acc + 8192) >> 14 = acc_h + (acc_l >> 14) exactly.  Checked here on the host for random and extreme operands, so
+    that the identity the kernel rests on is pinned without a GPU."""
+    rng = np.random.default_rng(14)
+
+    def split(c):
+        cl = ((c + 8192) & 16383) - 8192
+        return cl, (c - cl) >> 14
+    taps = np.concatenate([rng.integers(-32768, 32768, (20000, 5)), np.array([[-32768] * 5, [32767] * 5, [-32768, 32767, -32768, 32767, -32768]])])
+    vals = np.concatenate([rng.integers(-32768, 32768, (20000, 5)), np.array([[-32768] * 5, [-32768] * 5, [32767, -32768, 32767, -32768, 32767]])])
+    eff = taps.astype(np.int64).copy()
+    eff[:, 3:] = -eff[:, 3:]                                   # b0, b1, b2, -a1, -a2: the last two reach +32768
+    cl, ch = split(eff)
+    assert cl.min() >= -8192 and cl.max() <= 8191 and ch.min() >= -2 and ch.max() <= 2
+    assert np.array_equal((ch << 14) + cl, eff)
+    v = vals.astype(np.int64)
+    part_l = 8192 + np.cumsum(cl * v, axis=1)
+    part_h = np.cumsum(ch * v, axis=1)
+    assert np.abs(part_l).max() < 2 ** 31 and np.abs(part_h).max() < 2 ** 31      # no partial sum wraps
+    acc = (eff * v).sum(axis=1)
+    assert np.array_equal((acc + 8192) >> 14, part_h[:, -1] + (part_l[:, -1] >> 14))
