@@ -126,7 +126,10 @@ int sa_reserve(sa_handle *h, int max_batch);
  * such a pair was slower in overlap mode than without it).  The mapping is not exposed, so the library probes
  * candidate streams with a 100 us one-wave kernel: in sa_set_overlap() among themselves, and in the FIRST
  * overlapped process call made from a given caller stream against that stream -- that one call waits on the host
- * for the stream's earlier work and takes about a millisecond longer.  Best effort on a GPU busy with other work. */
+ * for the stream's earlier work and takes about a millisecond longer.  Best effort on a GPU busy with other work.
+ * The handle remembers ONE fitted caller stream (it is compared, never dereferenced: the caller may have destroyed it):
+ * overlapped calls that alternate between caller streams re-run the probe at every change -- keep a handle on one
+ * caller stream, as the one-handle-per-(GPU, stream) rule above says. */
 int sa_set_overlap(sa_handle *h, int depth /* 1..4 */);
 int sa_get_overlap(const sa_handle *h, int *depth);
 /* Introspection for tests: re-runs that probe on the handle's internal streams and `stream`;
