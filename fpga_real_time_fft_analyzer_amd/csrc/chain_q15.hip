@@ -86,17 +86,13 @@ constexpr int kTile = SA_Q15_TILE;    // samples per staging tile
 constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
-#ifndef SA_Q15_FPW
-#define SA_Q15_FPW 4
-#endif
-constexpr int kFramesPerWave = SA_Q15_FPW;   // one frame per 16-lane row (rows beyond it idle: A/B builds with 2)
+constexpr int kFramesPerWave = 4;      // one frame per 16-lane row (two frames per wave and two waves per SIMD: 1.47 x slower,
+                                       // profiles/r4_int_step_rate.txt)
 // moving a tile between memory and LDS: 16 bytes (8 samples) per lane, kTile / 8 lanes per frame row
 constexpr int kTileLanes = kTile / 8;                       // lanes that cover one row of a tile (32; 16 for 128-sample tiles)
-constexpr int kTileRows = (64 / kTileLanes) < kFramesPerWave ? (64 / kTileLanes) : kFramesPerWave;   // rows a wave covers per pass
-constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's frames
-constexpr bool kTileAllLanes = kTileRows * kTileLanes == 64;   // false only in A/B builds with fewer frames per wave than rows per pass
+constexpr int kTileRows = 64 / kTileLanes;                  // rows a wave covers per pass
+constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's four frames
 static_assert(kTile % 32 == 0 && kTileLanes <= 64 && kTileRows * kTilePasses == kFramesPerWave, "tile geometry");
-__device__ __forceinline__ bool tile_lane_on(int lane) { return kTileAllLanes || lane / kTileLanes < kTileRows; }
 
 // One biquad step, FPGA-exact Q7 form (new/filter_iir_cust.vhd:96-117):
 //   y = B2*x[n] + B1*x[n-1] + B0*x[n-2] - A0*y[n-2] - A1*y[n-1], each product >> 7 (floor), the sum
@@ -123,7 +119,7 @@ __device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, co
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
         r.x[i] = make_uint4(0, 0, 0, 0);
-        if (f < batch && tile_lane_on(lane)) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
+        if (f < batch) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
         r.c[i] = *reinterpret_cast<const uint4 *>(rom + n0 + col);
     }
 }
@@ -147,7 +143,7 @@ __device__ __forceinline__ void q15_store_tile(const Q15TileRegs &r, int16_t (*t
                 a = win_u16(lo16(xs[k]), lo16(cs[k]));
                 b = win_u16(hi16(xs[k]), hi16(cs[k]));
             }
-            if (tile_lane_on(lane)) *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
+            *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
         }
     }
 }
@@ -170,7 +166,6 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
         const int row = kTileRows * i + lane / kTileLanes;
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
-        if (!tile_lane_on(lane)) continue;
         const int sc = (src_col + col) & col_mask;      // 8-sample chunks: a ring wraps between chunks only
         uint4 ov;
         ov.x = *reinterpret_cast<const unsigned *>(&src[row][sc + 0]);
@@ -217,12 +212,8 @@ __global__ __launch_bounds__(64) void window_q15_kernel(const int16_t *__restric
 // 9 vector instructions per step, none depending on the one before it (q7_step); lanes: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample
 // T - 8 at step T: every group of 8 steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input
 // shift register.  Arithmetic identical to BiqQ7::step (new/filter_iir_cust.vhd:96-117).
-#ifndef SA_Q15_WAVES
-#define SA_Q15_WAVES 4
-#endif
-constexpr int kV2Waves = SA_Q15_WAVES;            // waves per workgroup (one per SIMD of the CU; A/B builds: 8 = two per SIMD)
-// lane 8 of every row that carries a frame
-constexpr unsigned long long kOutMask = kFramesPerWave >= 4 ? 0x0100010001000100ull : kFramesPerWave == 2 ? 0x0000000001000100ull : 0x0100ull;
+constexpr int kV2Waves = 4;                       // waves per workgroup: one per SIMD of the CU
+constexpr unsigned long long kOutMask = 0x0100010001000100ull;   // lane 8 of every row
 constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
 constexpr int kInPitch = kInRing + 8;
 
@@ -248,7 +239,7 @@ __device__ __forceinline__ void q15_window_into_ring(const Q15TileRegs &r, int16
             }
             o[q] = pack2(a, b);
         }
-        if (tile_lane_on(lane)) *reinterpret_cast<uint4 *>(&dst[row][col]) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(&dst[row][col]) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -310,68 +301,20 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
 // and stalls whole turns; which turns are lost depends on where the 8-byte instructions lie relative to the
 // instruction fetch (tools/ubench/q7_nop_sweep.py: the same nine instructions run 19.4, 21.7 or 24.1 ns per step
 // depending on a 4-byte s_nop in front of them or between them), so the loop is pinned: 64-byte aligned, nothing of
-// the compiler's inside it, `s_nop 0` where SA_Q7_NOPS (bit p = after instruction p of the block, order
-// H G B C A I D F E) says.  Per group: select the refill into t, request the next refill (16-bit LDS read, used
+// the compiler's inside it (fourteen placements of a 4-byte `s_nop 0` inside the block were timed on the real kernel,
+// 424-460 us: none beats the unpadded block in the order H G B C A I D F E).  Per group: select the refill into t, request the next refill (16-bit LDS read, used
 // one group later: lgkmcnt(2) = everything but the two stores behind it), eight blocks, lane 8's eight outputs
 // stored as dwords under an exec mask (restored five instructions before the next DPP read, as the hardware asks).
-#ifndef SA_Q7_NOPS
-#define SA_Q7_NOPS 0x000      // timed on the real kernel for every change of the loop's layout (tools/ab_q15.py)
-#endif
-#if SA_Q7_NOPS & 0x001
-#define SA_N0 "s_nop 0\n\t"
-#else
-#define SA_N0
-#endif
-#if SA_Q7_NOPS & 0x002
-#define SA_N1 "s_nop 0\n\t"
-#else
-#define SA_N1
-#endif
-#if SA_Q7_NOPS & 0x004
-#define SA_N2 "s_nop 0\n\t"
-#else
-#define SA_N2
-#endif
-#if SA_Q7_NOPS & 0x008
-#define SA_N3 "s_nop 0\n\t"
-#else
-#define SA_N3
-#endif
-#if SA_Q7_NOPS & 0x010
-#define SA_N4 "s_nop 0\n\t"
-#else
-#define SA_N4
-#endif
-#if SA_Q7_NOPS & 0x020
-#define SA_N5 "s_nop 0\n\t"
-#else
-#define SA_N5
-#endif
-#if SA_Q7_NOPS & 0x040
-#define SA_N6 "s_nop 0\n\t"
-#else
-#define SA_N6
-#endif
-#if SA_Q7_NOPS & 0x080
-#define SA_N7 "s_nop 0\n\t"
-#else
-#define SA_N7
-#endif
-#if SA_Q7_NOPS & 0x100
-#define SA_N8 "s_nop 0\n\t"
-#else
-#define SA_N8
-#endif
 #define SA_Q7_TBLOCK(Y, H1)                                                                                            \
-    "v_add_u32_sdwa " Y ", %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t" SA_N0   \
-    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N1  \
-    "v_mul_i32_i24_dpp %[p2], " H1 ", %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N2                           \
-    "v_mul_i32_i24_dpp %[p0], " Y ", %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N3                            \
-    "v_mad_i32_i24 %[p4], " Y ", %[nA1], %[k]\n\t" SA_N4                                                               \
-    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" SA_N5   \
-    "v_mul_i32_i24_dpp %[p1], " Y ", %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t" SA_N6                            \
-    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t" SA_N7  \
-    "v_mad_i32_i24 %[p3], " Y ", %[nA0], %[k]\n\t" SA_N8
+    "v_add_u32_sdwa " Y ", %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"   \
+    "v_add_u32_sdwa %[u], %[p1], %[p2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"  \
+    "v_mul_i32_i24_dpp %[p2], " H1 ", %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                           \
+    "v_mul_i32_i24_dpp %[p0], " Y ", %[cB2] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                            \
+    "v_mad_i32_i24 %[p4], " Y ", %[nA1], %[k]\n\t"                                                               \
+    "v_add_u32_sdwa %[s2], %[u], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"   \
+    "v_mul_i32_i24_dpp %[p1], " Y ", %[cB1] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                            \
+    "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"  \
+    "v_mad_i32_i24 %[p3], " Y ", %[nA0], %[k]\n\t"
 // The lane's last eight outputs live in v52..v59 inside the loop (named registers: the two 16-byte stores of lane 8
 // need them consecutive, and an asm operand cannot be addressed by sub-register); they are stored as sign-extended
 // dwords, the saturating pack to int16 happens once per sample in the flush, where all 64 lanes have work, instead
@@ -393,49 +336,6 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
 // block's p2 and p3.  Seven instructions per step, bit-identical results (new/filter_iir_cust.vhd:96-117 truncates every
 // product separately: a zero tap contributes a zero term).  The host picks this form per launch from the coefficient
 // bytes (sa_launch_filter_q15); any other upload runs the nine-instruction block.
-// Order and s_nop placement timed on the real kernel (tools/ab_q15.py, profiles/r3_q7_nb1_sweep.txt): SA_Q7_NB1_ORDER, SA_Q7_NB1_NOPS.
-#ifndef SA_Q7_NB1_ORDER
-#define SA_Q7_NB1_ORDER 3
-#endif
-#ifndef SA_Q7_NB1_NOPS
-#define SA_Q7_NB1_NOPS 0x00
-#endif
-#define SA_NBN(BIT) ((SA_Q7_NB1_NOPS >> (BIT)) & 1)
-#if SA_Q7_NB1_NOPS & 0x01
-#define SA_M0 "s_nop 0\n\t"
-#else
-#define SA_M0
-#endif
-#if SA_Q7_NB1_NOPS & 0x02
-#define SA_M1 "s_nop 0\n\t"
-#else
-#define SA_M1
-#endif
-#if SA_Q7_NB1_NOPS & 0x04
-#define SA_M2 "s_nop 0\n\t"
-#else
-#define SA_M2
-#endif
-#if SA_Q7_NB1_NOPS & 0x08
-#define SA_M3 "s_nop 0\n\t"
-#else
-#define SA_M3
-#endif
-#if SA_Q7_NB1_NOPS & 0x10
-#define SA_M4 "s_nop 0\n\t"
-#else
-#define SA_M4
-#endif
-#if SA_Q7_NB1_NOPS & 0x20
-#define SA_M5 "s_nop 0\n\t"
-#else
-#define SA_M5
-#endif
-#if SA_Q7_NB1_NOPS & 0x40
-#define SA_M6 "s_nop 0\n\t"
-#else
-#define SA_M6
-#endif
 #define SA_Q7I_H(Y) "v_add_u32_sdwa " Y ", %[s2], %[t] dst_sel:WORD_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"
 #define SA_Q7I_I "v_add_u32_sdwa %[s2], %[p2], %[p3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
 #define SA_Q7I_B(H1) "v_mul_i32_i24_dpp %[p2], " H1 ", %[cB0] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -443,19 +343,9 @@ __device__ __forceinline__ void lds_store16_masked(unsigned addr, q7_u4 v, unsig
 #define SA_Q7I_A(Y) "v_mad_i32_i24 %[p4], " Y ", %[nA1], %[k]\n\t"
 #define SA_Q7I_E(Y) "v_mad_i32_i24 %[p3], " Y ", %[nA0], %[k]\n\t"
 #define SA_Q7I_F "v_add_u32_sdwa %[t], %[p0], %[p4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-#if SA_Q7_NB1_ORDER == 0      // H I B C A E F
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_A(Y) SA_M4 SA_Q7I_E(Y) SA_M5 SA_Q7I_F SA_M6
-#elif SA_Q7_NB1_ORDER == 1    // H I B C A F E   (F one earlier: one instruction between F and the next block's H)
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_A(Y) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
-#elif SA_Q7_NB1_ORDER == 2    // H I A B C F E   (the feedback product first)
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_A(Y) SA_M2 SA_Q7I_B(H1) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
-#elif SA_Q7_NB1_ORDER == 3    // H I B A C E F
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_B(H1) SA_M2 SA_Q7I_A(Y) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_E(Y) SA_M5 SA_Q7I_F SA_M6
-#elif SA_Q7_NB1_ORDER == 4    // H I A C B F E   (every reader at least one instruction behind its writer, the DPP read two)
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_A(Y) SA_M2 SA_Q7I_C(Y) SA_M3 SA_Q7I_B(H1) SA_M4 SA_Q7I_F SA_M5 SA_Q7I_E(Y) SA_M6
-#else                         // H I E A C B F
-#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_M0 SA_Q7I_I SA_M1 SA_Q7I_E(Y) SA_M2 SA_Q7I_A(Y) SA_M3 SA_Q7I_C(Y) SA_M4 SA_Q7I_B(H1) SA_M5 SA_Q7I_F SA_M6
-#endif
+// order H I B A C E F (six orders and every single s_nop position were timed on the real kernel: this one, unpadded, is
+// the fastest; profiles/r3_fuzz_and_soak.txt, gpurun_out/ab_q7_nb1*.log)
+#define SA_Q7_NB1BLOCK(Y, H1) SA_Q7I_H(Y) SA_Q7I_I SA_Q7I_B(H1) SA_Q7I_A(Y) SA_Q7I_C(Y) SA_Q7I_E(Y) SA_Q7I_F
 #define SA_Q7_NB1GROUP(RD_OFF, WR_OFF0, WR_OFF1)                                                                       \
     "s_waitcnt lgkmcnt(2)\n\t"                                                                                         \
     "v_cndmask_b32_e64 %[t], %[t], %[xin], %[inm]\n\t"                                                                 \
@@ -536,7 +426,6 @@ __device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const i
         const int row = kTileRows * i + lane / kTileLanes;
         const int col = (lane % kTileLanes) * 8;
         const int f = f0 + row;
-        if (!tile_lane_on(lane)) continue;
         const int sc = (src_col + col) & (kRing - 1);       // 8-sample chunks: the ring wraps between chunks only
         const int4 a = *reinterpret_cast<const int4 *>(&src[row][sc]);
         const int4 b = *reinterpret_cast<const int4 *>(&src[row][sc + 4]);
@@ -562,7 +451,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
     int (*ring)[kRingPitch] = ring_all[wave];
-    const int fr = (lane >> 4) < kFramesPerWave ? (lane >> 4) : kFramesPerWave - 1;   // frame slot in this wave
+    const int fr = lane >> 4;           // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
     if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
@@ -747,7 +636,7 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
     int16_t (*ring)[kRingPitch] = ring_all[wave];
-    const int fr = (lane >> 4) < kFramesPerWave ? (lane >> 4) : kFramesPerWave - 1;   // frame slot in this wave
+    const int fr = lane >> 4;           // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row: 0 = input, 1..6 = sections 0..5, 7..8 = delay, 9..15 = input
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
     if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
