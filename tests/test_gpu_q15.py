@@ -61,15 +61,17 @@ def test_golden_digests_all_modes(ch, torch_mod):
     assert [sha(iq[i]) for i in range(4)] == list(g["iq_wide_sha"])
 
 
-@pytest.mark.parametrize("B,cmd", [(1, 0xB1), (7, 0x00), (9, 0xA1), (33, 0xB1), (64, 0x00)])
+@pytest.mark.parametrize("B,cmd", [(1, 0xB1), (7, 0x00), (9, 0xA1), (33, 0xB1), (64, 0x00), (1, 0xA2), (17, 0xA2), (65, 0xA2)])
 def test_bit_exact_vs_integer_model(ch, torch_mod, oracle, B, cmd):
     rng = np.random.default_rng(B * 7 + cmd)
     x = rng.integers(-2048, 2048, size=(B, N)).astype(np.int16)
     x[-1] = rng.integers(-32768, 32768, size=N)                      # one full-scale frame
     c12 = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
-    ch.load_coeffs_q7(c12)
+    sos14 = load_golden("g4_q15_frames.npz")["sos_q14"][:1 + B % 6]      # ragged batches (last wave, last workgroup partly
+    ch.load_coeffs_q7(c12)                                               # filled) for the wide cascade too, 1..6 sections
+    ch.load_sos_q14(sos14)
     ch.set_filter_mode(cmd)
-    ref_iq, ref_t = oracle.chain_q15(x, None, 0, cmd, c12, None, want_time=True)
+    ref_iq, ref_t = oracle.chain_q15(x, None, 0, cmd, c12, sos14, want_time=True)
     xd = _dev(torch_mod, x)
     assert np.array_equal(ch.filter_q15(xd).cpu().numpy(), ref_t)
     assert np.array_equal(ch.process_q15(xd).cpu().numpy(), ref_iq)
@@ -384,7 +386,8 @@ def test_batch_beyond_two_gib(ch, torch_mod):
     B = 36000
     x = torch.randint(-2048, 2048, (B, N), generator=gen, device="cuda", dtype=torch.int32).to(torch.int16)
     idx = torch.tensor([0, 1, 16383, 16384, 32767, 32768, B - 1], device="cuda")
-    for cmd in (0x00, 0xB1):
+    ch.load_sos_q14(load_golden("g4_q15_frames.npz")["sos_q14"])
+    for cmd in (0x00, 0xB1, 0xA2):
         ch.set_filter_mode(cmd)
         iq = ch.process_q15(x)
         assert torch.equal(iq[idx], ch.process_q15(x[idx].contiguous()))
