@@ -192,26 +192,22 @@ __global__ __launch_bounds__(64) void window_q15_kernel(const int16_t *__restric
     }
 }
 
-// ------------------------------------------------------------------------------------------ IIR, Q7, second form
-// The FPGA-exact cascade again, reorganised around what bounds it: the recursion is serial in time, one wave per
-// SIMD, so the time per step is the wave's issue rate (and behind it the dependent-instruction latency) times
-// the instructions per step.  Against filter_q15_kernel above this form
-//   * takes the three feed-forward products straight from the LEFT NEIGHBOUR's output registers with
-//     v_mul_i32_i24_dpp (row_ror:1): no separate cross-lane move, no x[n-1] / x[n-2] history registers, and the
-//     path from the neighbour's y to this lane's y is three instructions instead of four;
-//   * feeds the input through the lanes the cascade leaves idle: lanes 9..15 and 0 of the 16-lane row are identity
-//     stages forming a shift register, refilled with eight samples by ONE 16-bit LDS read and one select every
-//     eight steps (the first form spent two instructions per step on the input);
-//   * writes each step as one asm block in a fixed order (older products first), so the DPP read of the register
-//     written by the previous step's last add always has three instructions in front of it (the hardware asks
-//     for two wait states; the compiler cannot see into an asm block and must not be relied on to pad);
-//   * runs four waves per workgroup (16 frames): the dispatcher places the waves of one workgroup on the four
-//     SIMDs of one CU, and 256 workgroups = one per CU at B = 4096, instead of 1024 one-wave workgroups that land
-//     two to a SIMD on part of the chip whenever the dispatcher's SIMD pointer is not where the previous launch
-//     of the same kernel left it (profiles/r2_q15_placement.txt: 673 us back to back, 943 us after anything else).
-// 9 vector instructions per step, none depending on the one before it (q7_step); lanes: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample
-// T - 8 at step T: every group of 8 steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input
-// shift register.  Arithmetic identical to BiqQ7::step (new/filter_iir_cust.vhd:96-117).
+// ------------------------------------------------------------------------------------------ IIR, Q7 (FPGA-exact)
+// The cascade is organised around what bounds it: the recursion is serial in time, there is one wave per SIMD at
+// B = 4096, and a lone wave issues one vector instruction per ~2.5 ns whatever the instruction is
+// (profiles/r4_int_step_rate.txt) -- so the time per frame is 16 392 steps x the vector instructions of a step.
+//   * the three feed-forward products come straight from the LEFT NEIGHBOUR's output registers
+//     (v_mul_i32_i24_dpp row_ror:1): no cross-lane move, no x[n-1] / x[n-2] history registers;
+//   * the input travels through the lanes the cascade leaves idle: lanes 9..15 and 0 of the 16-lane row are identity
+//     stages forming a shift register, refilled with eight samples by ONE 16-bit LDS read and one select per eight steps;
+//   * every step is one asm block in a fixed order, so the DPP read of a register the neighbour has just written always
+//     has the two wait states the hardware asks for (the compiler cannot see into an asm block and does not pad);
+//   * four waves per workgroup (16 frames): the dispatcher places the waves of one workgroup on the four SIMDs of one CU,
+//     256 workgroups = one per CU at B = 4096.  (1 024 one-wave workgroups land two to a SIMD on part of the chip whenever
+//     another kernel ran before: 673 us back to back, 943 us after anything else -- profiles/r2_q15_placement.txt.)
+// Lanes of a row: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample T - 8 at step T: every group of 8
+// steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input shift register.  9 vector instructions per step,
+// 7 when tap B1 is zero in both coefficient sets.  What was tried on this step and did not pay: Appendix B of DESIGN.md.
 constexpr int kV2Waves = 4;                       // waves per workgroup: one per SIMD of the CU
 constexpr unsigned long long kOutMask = 0x0100010001000100ull;   // lane 8 of every row
 constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
