@@ -271,6 +271,32 @@ def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
             ch.set_filter_mode(cmd)
             ref = oracle.chain_q15(xf, rom, wm, cmd, None, None)
             assert np.array_equal(ch.process_q15(_dev(torch_mod, xf)).cpu().numpy(), ref), (wm, cmd)
+    # The same corner through the staging of the cascade kernels (the tests above reach it through the FFT-side window only):
+    # a ROM whose -32768 entries sit in a few tiles, full-scale samples with -32768 at those very positions and at others,
+    # all three cascade kernels, the 256- and the 128-sample-tile builds (depth 2), time series and frames
+    rom2 = rng.integers(-32767, 32768, size=N).astype(np.int16)
+    hot = np.concatenate([np.arange(100, 130), np.arange(5000, 5003), np.arange(8191, 8194), np.arange(16380, 16384)])
+    rom2[hot] = -32768
+    xg = rng.integers(-32768, 32768, size=(5, N)).astype(np.int16)
+    xg[:, hot] = -32768
+    xg[:, 777::1001] = -32768
+    ch.set_window_q15(rom2)
+    ch.set_window_mode_q15(0)
+    gui = np.array([0, 1, 0, 64, -67, 19, 64, 127, 64, 64, -85, 40], np.int8)
+    sos14 = load_golden("g4_q15_frames.npz")["sos_q14"]
+    ch.load_coeffs_q7(gui)
+    ch.load_sos_q14(sos14)
+    for depth in (1, 2):
+        ch.set_overlap(depth)
+        for cmd in (0x00, 0xA1, 0xA2):
+            ch.set_filter_mode(cmd)
+            ref_iq, ref_t = oracle.chain_q15(xg, rom2, 0, cmd, gui, sos14, want_time=True)
+            got = ch.process_q15(_dev(torch_mod, xg))
+            ch.flush()
+            assert np.array_equal(got.cpu().numpy(), ref_iq), (depth, cmd)
+            if depth == 1:
+                assert np.array_equal(ch.filter_q15(_dev(torch_mod, xg)).cpu().numpy(), ref_t), cmd
+    ch.set_overlap(1)
     ch.set_filter_mode(0xB1)
     ch.set_window_q15(None)
     ch.set_window_mode_q15(0)
