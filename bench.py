@@ -344,6 +344,8 @@ class GpuWorkload:
             r = self._measure(step256, nb, BYTES_PER_FRAME_F32, 200, 1)
             r["bytes_per_frame"] = BYTES_PER_FRAME_F32
             r["workload"] = "BASELINE.json configs[1]: batch=256 x 16K fp32, Hann + 16K FFT + magnitude, IIR bypassed, stream-ordered"
+            # (two 256-frame launches in flight do not help from Python: 15.3 us per step against 10.5 -- an overlapped call
+            #  costs the host 14-18 us, more than the 10 us kernel it launches; a 512-frame batch is the way to fill the CUs)
             out["config2_b256_bypass"] = r
         # the same bypassed chain on the headline's batch (not a BASELINE configuration; SURVEY hypothesis H6 names the
         # bypassed chain as the place where 0.70 of the HBM roofline is realistic first)
