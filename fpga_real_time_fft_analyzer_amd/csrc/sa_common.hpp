@@ -118,8 +118,6 @@ struct SaLaunchEv {
 };
 hipError_t sa_launch_chain_f32(const float *in, void *out, int batch, int out_kind, const SaF32Tables &t,
                                hipStream_t stream, SaLaunchEv ev);
-// the bypassed chain (no IIR), full-spectrum magnitudes, for small batches: 512 threads per frame (chain_f32_small.hip)
-hipError_t sa_launch_chain_f32_small(const float *in, float *out, int batch, const SaF32Tables &t, hipStream_t stream, SaLaunchEv ev);
 // the same chain on int16 samples (chain_f32_i16.hip): x = float(sample) * in_scale, then exactly the float32 path
 hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out, int batch, int out_kind, const SaF32Tables &t,
                                    hipStream_t stream, SaLaunchEv ev);

@@ -1298,14 +1298,6 @@ int sa_process_f32(sa_handle *h, const float *in, void *out, int batch, int out_
         t.lanetab = h->d_lt_custom;
         t.iir = &h->plan_custom;
     }
-#ifdef SA_SMALL_BATCH_MAX
-    // Small batches of the bypassed chain with the full-spectrum output (BASELINE config 2: B = 256 = one frame per CU):
-    // two waves per SIMD on every frame instead of one (chain_f32_small.hip)
-    if (t.iir == nullptr && out_kind == SA_OUT_MAG_FULL && batch <= SA_SMALL_BATCH_MAX) {
-        SA_HIP(h, sa_launch_chain_f32_small(in, reinterpret_cast<float *>(out), batch, t, c.stream, {c.start, c.stop}));
-        return end_call(h, c);
-    }
-#endif
     SA_HIP(h, sa_launch_chain_f32(in, out, batch, out_kind, t, c.stream, {c.start, c.stop}));
     return end_call(h, c);
 }
