@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the integer cascade kernels mode by mode at B frames, stream-ordered: the cascade alone (sa_filter_q15) and the
-whole integer chain (sa_process_q15), per launch by HIP events, after a warm-up.  usage: q15_modes.py [B] [LIB]"""
+whole integer chain (sa_process_q15), per call from the launches' own start / stop events (sa_set_profiling), after a warm-up.  usage: q15_modes.py [B] [LIB]"""
 import os
 import sys
 
@@ -35,15 +35,11 @@ for name, cmd in (("0x00 default (7-instruction step)", 0x00), ("0xA1 GUI upload
     for label, fn, o in (("cascade", ch.filter_q15, ot), ("chain", ch.process_q15, oq)):
         for k in range(3):
             fn(xs[k % 3], out=o)
-        evs = []
+        ch.set_profiling(12)                              # device time of each call from the launch's own events
         for k in range(12):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
             fn(xs[k % 3], out=o)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        ts = sorted(v * 1e3 for v in ch.profile_read(12))
+        ch.set_profiling(0)
         if label == "chain":
             import hashlib
             digest = hashlib.sha256(o[:64].cpu().numpy().tobytes()).hexdigest()[:12]

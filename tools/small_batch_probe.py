@@ -1,16 +1,29 @@
-import os, sys, ctypes as C
-import numpy as np, torch
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
-from fpga_real_time_fft_analyzer_amd import abi
-if len(sys.argv) > 2: abi.LIB_PATH = os.path.join(os.path.dirname(abi.LIB_PATH), sys.argv[2])
-from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain
-B = int(sys.argv[1])
-ch = SpectrumChain(0)
-x = torch.randn(4096, 16384, device="cuda"); o = torch.empty(4096, 16384, device="cuda")
+#!/usr/bin/env python3
+"""Kernel time of the bypassed float chain at tiny batches (one frame, 16, 64, 256), from the launches' own start / stop
+events (sa_set_profiling): how long ONE frame takes on an otherwise idle chip is the floor of BASELINE config 2.
+usage: small_batch_probe.py B [library file in the package directory]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fpga_real_time_fft_analyzer_amd import abi  # noqa: E402
+if len(sys.argv) > 2:
+    abi.LIB_PATH = os.path.join(os.path.dirname(abi.LIB_PATH), sys.argv[2])
+from fpga_real_time_fft_analyzer_amd.chain import SpectrumChain  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ch = SpectrumChain(0)                                   # power-on mode: IIR bypassed
+x = torch.randn(4096, 16384, device="cuda")
+o = torch.empty(4096, 16384, device="cuda")
 ch.set_profiling(64)
-for rep in range(30):
-    for j in range(0, 4096 - B + 1, B):
-        ch.process_f32(x[j:j+B], out=o[j:j+B])
-        if (j // B) % 16 == 15: break
+for rep in range(30):                                    # rotating slices of a 256 MiB pool: nothing stays cached
+    for k, j in enumerate(range(0, 4096 - B + 1, B)):
+        ch.process_f32(x[j:j + B], out=o[j:j + B])
+        if k == 15:
+            break
 ms = ch.profile_read(64)
-print(f"{sys.argv[2] if len(sys.argv) > 2 else 'product':24s} B={B:4d}: kernel median {np.median(ms)*1e3:7.2f} us  min {min(ms)*1e3:7.2f}")
+print(f"{sys.argv[2] if len(sys.argv) > 2 else 'product':24s} B={B:4d}: kernel median {np.median(ms) * 1e3:7.2f} us  min {min(ms) * 1e3:7.2f}")
