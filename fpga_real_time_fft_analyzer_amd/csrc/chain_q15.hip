@@ -734,6 +734,17 @@ __device__ __forceinline__ unsigned fx_twiddle2(unsigned p, unsigned w)
     return sat_pack2(pr, (UNIFORM ? fx_dot2_s(p, w) : fx_dot2(p, w)) >> 15);
 }
 
+// the three twiddles of one butterfly of a per-lane stage: one 32-byte record (SaQ15Tables::twrec), read as 16 + 8 bytes
+struct SaTw3 {
+    uint2 w1, w2, w3;
+};
+__device__ __forceinline__ SaTw3 fx_twrec(const uint4 *__restrict__ twrec, int r)
+{
+    const uint4 a = twrec[2 * r];
+    const uint2 b = *reinterpret_cast<const uint2 *>(&twrec[2 * r + 1]);
+    return {make_uint2(a.x, a.y), make_uint2(a.z, a.w), b};
+}
+
 // one radix-4 DIF butterfly of SA-FXFFT-1 on packed (re, im) int16 pairs: 32-bit sums, >> 2 (truncation),
 // Q15 twiddles on outputs 1..3 (exact pass-through when the exponent is 0), saturation to int16
 // UNIFORM: the twiddles are the same for the whole wave (scalar loads, or compile-time exponents)
@@ -804,22 +815,25 @@ __device__ __forceinline__ void fx_butterfly_real(int a, int b, int c, int d, ui
     }
 }
 
-// SA-FXFFT-1 with 1024 threads per frame: 16 positions per thread (t + 1024 m), stages 0..4 through LDS, stages 5
-// and 6 in registers.  (Round 1 and most of round 2 ran 256 threads x 64 positions, stages 4..6 in registers: one
-// LDS pass fewer, but 120 registers per thread.  The frame's 64 KiB of LDS allow two workgroups per CU either way:
-// that was 2 waves per SIMD, the waves spent a quarter of their life in s_waitcnt behind a barrier with one other
-// wave to cover for them; this is 8 waves per SIMD at 52 registers, 192 -> 155-172 us.)
+// SA-FXFFT-1 with 1024 threads per frame: 16 positions per thread (t + 1024 m); the seven radix-4 stages run as four
+// register passes -- stage 0 from global memory, then (1,2), (3,4), (5,6) -- with one LDS exchange between passes.
+// (Round 1 and most of round 2 ran 256 threads x 64 positions, stages 4..6 in registers: 120 registers per thread, 2 waves
+// per SIMD, a quarter of a wave's life in s_waitcnt behind a barrier with one other wave to cover: 192 us.  Rounds 2-3 ran
+// 1024 threads with ONE stage per LDS exchange for stages 0..4: 155-158 us.  Pairing the stages (three exchanges instead
+// of five, the second stage of a pair shares one twiddle triple among a thread's four butterflies) and reading a lane's
+// three twiddles as one 32-byte record instead of three strided gathers: 126-130 us, profiles/r4_fft_q15_passes.txt.)
 //   7 radix-4 DIF stages, Stockham addressing:
 //   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
 //   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
 //   output i' at (j' << (2s+2)) | (i' << 2s) | kappa; twiddle exponent i' * j' * 4^s.
+// 8 waves per SIMD (two frames per CU, 64 KiB of LDS each) need <= 64 registers: the second launch bound asks for that.
 constexpr int kFftWide = 1024;
 
 template <bool WINDOW>
-__global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__restrict__ in,
+__global__ __launch_bounds__(kFftWide, 8) void fft_q15_kernel(const int16_t *__restrict__ in,
                                                                int16_t *__restrict__ out_iq, int batch,
                                                                SaQ15Params prm, const int16_t *__restrict__ rom,
-                                                               const uint2 *__restrict__ tw)
+                                                               const uint2 *__restrict__ tw, const uint4 *__restrict__ twrec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
     unsigned *buf = reinterpret_cast<unsigned *>(smem_q);     // [16384] packed (re, im)
@@ -847,39 +861,79 @@ __global__ __launch_bounds__(kFftWide, 2) void fft_q15_kernel(const int16_t *__r
         for (int u = 0; u < 4; ++u) {
             const int bf = t + kFftWide * u;                   // j' = bf, kappa = 0, e1 = bf
             unsigned o[4];
-            fx_butterfly_real(x[u], x[u + 4], x[u + 8], x[u + 12], tw[bf], tw[2 * bf].x, tw[3 * bf], bf == 0, o, u == 3, u == 1);
+            const SaTw3 w = fx_twrec(twrec, bf);
+            fx_butterfly_real(x[u], x[u + 4], x[u + 8], x[u + 12], w.w1, w.w2.x, w.w3, bf == 0, o, u == 3, u == 1);
             *reinterpret_cast<uint4 *>(buf + 4 * bf) = make_uint4(o[0], o[1], o[2], o[3]);
         }
         __syncthreads();
     }
 
-    // ---- stages 1..4: butterfly bf = t + 1024 u, u = 0..3; every output goes to another thread (one LDS pass each).
-    // From stage 3 on j' = bf >> 2s is the same for the whole wave: scalar twiddle loads.
+    // ---- stages 1..4 as two register passes of two stages each.  A thread that runs the stage-s butterflies
+    // bf = t + 1024 u (u = 0..3) holds, in output i' of butterfly u, input u of the stage-(s+1) butterfly
+    // ((j' mod 4^(5-s)) << (2s+2)) | (i' << 2s) | kappa -- its own four next butterflies, which all share ONE twiddle
+    // exponent (j'' = (t >> 2s) mod 4^(5-s) does not depend on i').  One LDS exchange per two stages instead of one per
+    // stage, a quarter of the twiddle loads in the second stage of a pass.
+    //   outputs of the pass: pos = (j'' << (2s+4)) | (i'' << (2s+2)) | (i' << 2s) | kappa
+    // Pass (1,2) writes with kappa = t & 3 in the bank bits: the words are stored at pos ^ ((j'' & 15) << 2), which spreads
+    // the 16 values of j'' in a wave over the banks (conflict-free), and pass (3,4) reads t + 1024 m through the same
+    // exchange of bits (there it permutes the lanes of a wave: conflict-free as well).
     unsigned v[16];
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    {
 #pragma unroll
-    for (int s = 1; s < 5; ++s) {
-        const int sh = 2 * s;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = buf[t + kFftWide * m];     // m = u + 4 i
+        for (int m = 0; m < 16; ++m) v[m] = buf[t + kFftWide * m];
         __syncthreads();
+        unsigned x[16];                                        // x[4 i' + u]
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int bf = t + kFftWide * u;
-            const int jp = (s >= 3) ? (__builtin_amdgcn_readfirstlane(t >> sh) + (kFftWide >> sh) * u) : (bf >> sh);
-            const int kap = bf & ((1 << sh) - 1);
-            const int e1 = jp << sh;
+            const int e1 = ((t + kFftWide * u) >> 2) << 2;
             unsigned o[4];
-            // exponents with wi = -32768 (see fx_butterfly): output 1 in stage 1 at u = 3, output 3 at u = 1,
-            // output 2 at u = 1 or 2 in stage 1 and at u = 2 from stage 2 on
-            if (s >= 3)
-                fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o, false, u == 2,
-                                   false);
-            else
-                fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o, s < 2 && u == 3,
-                             s < 2 ? (u == 1 || u == 2) : (u == 2), s < 2 && u == 1);
-            const int ob = (jp << (sh + 2)) | kap;
+            // exponents with wi = -32768 (see fx_butterfly): output 1 at u = 3, output 3 at u = 1, output 2 at u = 1 or 2
+            const SaTw3 w = fx_twrec(twrec, 4096 + (e1 >> 2));
+            fx_butterfly(v[u], v[u + 4], v[u + 8], v[u + 12], w.w1, w.w2, w.w3, e1 == 0, o, u == 3, u == 1 || u == 2, u == 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) buf[ob + (i << sh)] = o[i];
+            for (int i = 0; i < 4; ++i) x[4 * i + u] = o[i];
+        }
+        // stage 2: j'' = (t >> 2) & 255, exponent 16 j'' (never in 4082..4095; 3 e never in 4083..4110; 2 e = 4096 for
+        // j'' = 128, i.e. threads 512..515: wave 8 takes the two-multiply form for output 2)
+        const int j2 = (t >> 2) & 255, e2 = j2 << 4;
+        const SaTw3 w2 = fx_twrec(twrec, 5120 + j2);
+        const uint2 a1 = w2.w1, a2 = w2.w2, a3 = w2.w3;
+        const int ob = ((j2 << 6) | (t & 3)) ^ ((j2 & 15) << 2);
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip) {
+            unsigned o[4];
+            if (wave == 8) fx_butterfly(x[4 * ip], x[4 * ip + 1], x[4 * ip + 2], x[4 * ip + 3], a1, a2, a3, false, o, false, true, false);
+            else fx_butterfly(x[4 * ip], x[4 * ip + 1], x[4 * ip + 2], x[4 * ip + 3], a1, a2, a3, e2 == 0, o, false, false, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[ob ^ ((4 * i + ip) << 2)] = o[i];
+        }
+        __syncthreads();
+    }
+    {
+        // pass (3,4): scalar twiddles in both stages (j' = wave + 16 u, then j'' = wave)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = buf[(t + kFftWide * m) ^ (wave << 2)];
+        __syncthreads();
+        unsigned x[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e1 = (wave + 16 * u) << 6;
+            unsigned o[4];
+            fx_butterfly<true>(v[u], v[u + 4], v[u + 8], v[u + 12], tw[e1], tw[2 * e1], tw[3 * e1], e1 == 0, o, false, u == 2, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[4 * i + u] = o[i];
+        }
+        const int e2 = wave << 8;                              // 2 e = 4096 for wave 8
+        const uint2 a1 = tw[e2], a2 = tw[2 * e2], a3 = tw[3 * e2];
+        const int ob = (wave << 10) | (t & 63);
+#pragma unroll
+        for (int ip = 0; ip < 4; ++ip) {
+            unsigned o[4];
+            if (wave == 8) fx_butterfly<true>(x[4 * ip], x[4 * ip + 1], x[4 * ip + 2], x[4 * ip + 3], a1, a2, a3, false, o, false, true, false);
+            else fx_butterfly<true>(x[4 * ip], x[4 * ip + 1], x[4 * ip + 2], x[4 * ip + 3], a1, a2, a3, e2 == 0, o, false, false, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[ob | ((4 * i + ip) << 6)] = o[i];
         }
         __syncthreads();
     }
@@ -951,7 +1005,7 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     auto k = apply_window ? fft_q15_kernel<true> : fft_q15_kernel<false>;
     const hipError_t e = sa_set_dyn_lds_once(reinterpret_cast<const void *>(k), lds);
     if (e != hipSuccess) return e;
-    hipExtLaunchKernelGGL(k, grid, block, lds, stream, ev.start, ev.stop, 0, in_time, out_iq, batch, p, t.rom, t.tw);
+    hipExtLaunchKernelGGL(k, grid, block, lds, stream, ev.start, ev.stop, 0, in_time, out_iq, batch, p, t.rom, t.tw, t.twrec);
     return hipGetLastError();
 }
 #endif

@@ -125,7 +125,10 @@ hipError_t sa_launch_chain_f32_i16(const int16_t *in, float in_scale, void *out,
 struct SaQ15Tables {
     const int16_t *rom;        // [16384] window ROM
     const uint2 *tw;           // [16384] Q15 twiddles as packed int16 pairs: x = (wr, wi), y = (-wi, wr)
+    const uint4 *twrec;        // [2 * kSaTwRecs] the per-lane twiddles of FFT stages 0..2 as 32-byte records {w1, w2, w3, pad}:
+                               // records 0..4095: stage 0, exponent bf; 4096..5119: stage 1, exponent 4 j'; 5120..5375: stage 2, 16 j''
 };
+constexpr int kSaTwRecs = 4096 + 1024 + 256;
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
                                 const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);

@@ -260,6 +260,7 @@ struct sa_handle {
     SaIirLaneTab *d_lt_default = nullptr, *d_lt_custom = nullptr;
     int16_t *d_rom = nullptr;
     uint2 *d_twq = nullptr;          // SA-FXFFT-1 twiddles, {(wr, wi), (-wi, wr)} packed int16 pairs
+    uint4 *d_twrec = nullptr;        // the same words regrouped per butterfly for the per-lane stages (SaQ15Tables::twrec)
     // Q15 IIR workspace, one per launch slot (slot 0 = ordered mode; overlap mode uses slots 0..depth-1).  A
     // workspace that is outgrown is retired, not freed (hipFree synchronises the whole device; launches in flight
     // may still use it): freed in sa_destroy.  Growth is geometric so that the retired total stays below the live one.
@@ -783,6 +784,7 @@ int sa_create(int device, sa_handle **out)
     SA_HIPC(hipMalloc(&h->d_lt_custom, sizeof(SaIirLaneTab)));
     SA_HIPC(hipMalloc(&h->d_rom, sizeof(int16_t) * SA_NPTS));
     SA_HIPC(hipMalloc(&h->d_twq, sizeof(uint2) * SA_NPTS));
+    SA_HIPC(hipMalloc(&h->d_twrec, sizeof(uint4) * 2 * kSaTwRecs));
 
     // float tables
     {
@@ -864,6 +866,15 @@ int sa_create(int device, sa_handle **out)
             tq[m].y = ((uint32_t)nwi & 0xFFFFu) | ((uint32_t)wr << 16);
         }
         SA_HIPC(hipMemcpy(h->d_twq, tq.data(), sizeof(uint2) * SA_NPTS, hipMemcpyHostToDevice));
+        // One 32-byte record {w(e), w(2e), w(3e), pad} per butterfly of the stages whose exponents differ from lane to
+        // lane: a lane's three twiddles are one contiguous read instead of three gathers at strides 8, 16 and 24 bytes.
+        std::vector<uint4> rec(2 * kSaTwRecs);
+        for (int r = 0; r < kSaTwRecs; ++r) {
+            const int e = r < 4096 ? r : (r < 5120 ? 4 * (r - 4096) : 16 * (r - 5120));
+            rec[2 * r] = make_uint4(tq[e].x, tq[e].y, tq[2 * e].x, tq[2 * e].y);
+            rec[2 * r + 1] = make_uint4(tq[3 * e].x, tq[3 * e].y, 0u, 0u);
+        }
+        SA_HIPC(hipMemcpy(h->d_twrec, rec.data(), sizeof(uint4) * 2 * kSaTwRecs, hipMemcpyHostToDevice));
     }
     SA_HIPC(hipDeviceSynchronize());          // creation only: the blocking copies above are complete
 #undef SA_HIPC
@@ -902,6 +913,7 @@ int sa_destroy(sa_handle *h)
     (void)hipFree(h->d_lt_custom);
     (void)hipFree(h->d_rom);
     (void)hipFree(h->d_twq);
+    (void)hipFree(h->d_twrec);
     for (int i = 0; i < sa_handle::kMaxOverlap; ++i) (void)hipFree(h->d_work[i]);
     for (void *p : h->retired) (void)hipFree(p);
     delete h;
@@ -1233,7 +1245,7 @@ int sa_filter_q15(sa_handle *h, const int16_t *in, int16_t *out_time, int batch,
     { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
-    const SaQ15Tables t = {h->d_rom, h->d_twq};
+    const SaQ15Tables t = {h->d_rom, h->d_twq, h->d_twrec};
     SA_HIP(h, sa_launch_filter_q15(in, out_time, batch, p, t, c.stream, {c.start, c.stop}));
     return end_call(h, c);
 }
@@ -1249,7 +1261,7 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
     { const int rc = begin_call(h, (hipStream_t)stream, &c); if (rc != SA_OK) return rc; }
     SaQ15Params p;
     q15_params(h, &p);
-    const SaQ15Tables t = {h->d_rom, h->d_twq};
+    const SaQ15Tables t = {h->d_rom, h->d_twq, h->d_twrec};
     if (p.filter == SA_FILTER_NONE) {
         SA_HIP(h, sa_launch_fft_q15(in, out_iq, batch, true, p, t, c.stream, {c.start, c.stop}));
         return end_call(h, c);

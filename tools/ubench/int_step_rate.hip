@@ -178,7 +178,22 @@ template <int KIND>
 __global__ void k_enc(int *out, int ngroups, int cc)
 {
     int a0 = cc, a1 = cc + 1, a2 = cc + 2, a3 = cc + 3, b = threadIdx.x;
+    if (cc >= 100 && (threadIdx.x & 32)) return;          // cc >= 100: only the low 32 lanes of every wave stay active
     for (int g = 0; g < ngroups; ++g) {
+        if (KIND == 4)
+            asm volatile(REP16("v_add_u32_sdwa %0, %4, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\tv_add_u32_sdwa %1, %4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                               "v_add_u32_sdwa %2, %4, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\tv_add_u32_sdwa %3, %4, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        if (KIND == 5)
+            asm volatile(REP16("v_mad_i32_i24 %0, %4, %0, %0\n\tv_mad_i32_i24 %1, %4, %1, %1\n\tv_mad_i32_i24 %2, %4, %2, %2\n\tv_mad_i32_i24 %3, %4, %3, %3\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        if (KIND == 6)
+            asm volatile(REP16("v_dot2_i32_i16 %0, %4, %0, %0\n\tv_dot2_i32_i16 %1, %4, %1, %1\n\tv_dot2_i32_i16 %2, %4, %2, %2\n\tv_dot2_i32_i16 %3, %4, %3, %3\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        if (KIND == 7)
+            asm volatile(REP16("v_mov_b32_dpp %0, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mov_b32_dpp %2, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
         if (KIND == 0)
             asm volatile(REP16("v_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %2, %4, %2\n\tv_add_u32_e32 %3, %4, %3\n\t")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void k_cvt_dot(int *out, int ngroups, int cc) 
 int main()
 {
     int *out;
-    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&out, 512 * 1024 * 4);
     const int ngroups = 2049;      // 16 392 steps, as one frame
     struct K { const char *name; void (*fn)(int *, int, int); int instr_per_group; int steps_per_group; };
     const K ks[] = {
@@ -280,16 +295,35 @@ int main()
         printf("%-44s %7.1f us for 16 392 steps = %5.2f ns per step = %5.2f ns per instruction\n", k.name, best * 1e3,
                best * 1e6 / (ngroups * 8.0), best * 1e6 / (ngroups * (double)k.instr_per_group));
     }
+    // the same blocks with TWO workgroups per CU: two waves on every SIMD (what a batch of 8 192 frames, or two frames per
+    // wave instead of four, would look like)
+    for (const K &k : ks) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 20; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k.fn, dim3(512), dim3(256), 0, 0, out, ngroups, 3);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("2 waves/SIMD: %-44s %7.1f us for 16 392 steps = %5.2f ns per step per wave\n", k.name, best * 1e3,
+               best * 1e6 / (ngroups * 8.0));
+    }
     // encoding-size probes: ns per instruction and bytes per ns, one and two waves per SIMD
     struct E { const char *name; void (*fn)(int *, int, int); int bytes; };
     const E es[] = {{"64 x v_add_u32 e32 (4 bytes)", k_enc<0>, 4 * 64}, {"64 x v_add_u32 e64 (8 bytes)", k_enc<1>, 8 * 64},
-                    {"64 x alternating e32 / e64", k_enc<2>, 6 * 64}, {"64 x v_mul_i32_i24_dpp (8 bytes)", k_enc<3>, 8 * 64}};
-    for (int threads = 256; threads <= 512; threads += 256)
+                    {"64 x alternating e32 / e64", k_enc<2>, 6 * 64}, {"64 x v_mul_i32_i24_dpp (8 bytes)", k_enc<3>, 8 * 64},
+                    {"64 x v_add_u32_sdwa (8 bytes)", k_enc<4>, 8 * 64}, {"64 x v_mad_i32_i24 (8 bytes)", k_enc<5>, 8 * 64},
+                    {"64 x v_dot2_i32_i16 (8 bytes)", k_enc<6>, 8 * 64}, {"64 x v_mov_b32_dpp (8 bytes)", k_enc<7>, 8 * 64}};
+    for (int half = 0; half < 2; ++half)
+    for (int threads = 256; threads <= 1024; threads += 256)
         for (const E &e : es) {
             float best = 1e9f;
+            if (half) printf("low 32 lanes only: ");
             for (int rep = 0; rep < 30; ++rep) {
                 hipEventRecord(e0, 0);
-                hipLaunchKernelGGL(e.fn, dim3(256), dim3(threads), 0, 0, out, 4096, 3);
+                hipLaunchKernelGGL(e.fn, dim3(256), dim3(threads), 0, 0, out, 4096, half ? 103 : 3);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
