@@ -159,7 +159,7 @@ __device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, c
 
 template <int PITCH>
 __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const int16_t (*src)[PITCH], int src_col,
-                                               int f0, int batch, int n0, int lane, int col_mask = 0x7fffffff)
+                                               int f0, int batch, int n0, int lane, int col_mask = 0x7fffffff, int ncols = kTile)
 {
 #pragma unroll
     for (int i = 0; i < kTilePasses; ++i) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
         ov.y = *reinterpret_cast<const unsigned *>(&src[row][sc + 2]);
         ov.z = *reinterpret_cast<const unsigned *>(&src[row][sc + 4]);
         ov.w = *reinterpret_cast<const unsigned *>(&src[row][sc + 6]);
-        if (f < batch) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
+        if (f < batch && n0 + col >= 0 && col < ncols) *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) = ov;
     }
 }
 
@@ -202,13 +202,16 @@ __global__ __launch_bounds__(64) void window_q15_kernel(const int16_t *__restric
 //     stages forming a shift register, refilled with eight samples by ONE 16-bit LDS read and one select per eight steps;
 //   * every step is one asm block in a fixed order, so the DPP read of a register the neighbour has just written always
 //     has the two wait states the hardware asks for (the compiler cannot see into an asm block and does not pad);
-//   * four waves per workgroup (16 frames): the dispatcher places the waves of one workgroup on the four SIMDs of one CU,
-//     256 workgroups = one per CU at B = 4096.  (1 024 one-wave workgroups land two to a SIMD on part of the chip whenever
+//   * four cascade waves per workgroup (16 frames): the dispatcher places the waves of one workgroup on the four SIMDs of one
+//     CU, 256 workgroups = one per CU at B = 4096.  (1 024 one-wave workgroups land two to a SIMD on part of the chip whenever
 //     another kernel ran before: 673 us back to back, 943 us after anything else -- profiles/r2_q15_placement.txt.)
+//   * four HELPER waves per workgroup (waves 4..7, one beside each cascade wave) do the staging and the flushing
+//     (q15_helper_wave): a lone wave's unused issue turns are the only place where that work costs nothing.
 // Lanes of a row: 0 = input, 1..6 = sections 0..5, 7..8 = delay (lane 8 emits sample T - 8 at step T: every group of 8
 // steps ends with 8 consecutive, 16-byte aligned outputs), 9..15 = input shift register.  9 vector instructions per step,
 // 7 when tap B1 is zero in both coefficient sets.  What was tried on this step and did not pay: Appendix B of DESIGN.md.
-constexpr int kV2Waves = 4;                       // waves per workgroup: one per SIMD of the CU
+constexpr int kV2Waves = 4;                       // cascade waves per workgroup: one per SIMD of the CU
+constexpr int kWgWaves = 2 * kV2Waves;            // + one helper wave per cascade wave (staging and flushing, see q15_helper_wave)
 constexpr unsigned long long kOutMask = 0x0100010001000100ull;   // lane 8 of every row
 constexpr int kInRing = 2 * kTile;                // input ring per frame: the tile in use + the one before it
 constexpr int kInPitch = kInRing + 8;
@@ -415,8 +418,9 @@ __device__ __forceinline__ void q7_tile(int (&y)[8], Q7Carry &c, unsigned xa, un
 // flush one tile of the dword ring: 8 samples per lane, packed to int16 with saturation (exact: the values are
 // sign-extended 16-bit numbers) and stored as 16 bytes
 __device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const int (*src)[kRingPitch], int src_col, int f0,
-                                              int batch, int n0, int lane)
+                                              int batch, int n0, int lane, int ncols = kTile)
 {
+    // n0 may be -8 (the helper's spans start eight samples early: q7 helper waves below) and ncols may be 8 (the tail)
 #pragma unroll
     for (int i = 0; i < kTilePasses; ++i) {
         const int row = kTileRows * i + lane / kTileLanes;
@@ -425,7 +429,7 @@ __device__ __forceinline__ void q7_flush_tile(int16_t *__restrict__ out, const i
         const int sc = (src_col + col) & (kRing - 1);       // 8-sample chunks: the ring wraps between chunks only
         const int4 a = *reinterpret_cast<const int4 *>(&src[row][sc]);
         const int4 b = *reinterpret_cast<const int4 *>(&src[row][sc + 4]);
-        if (f < batch)
+        if (f < batch && n0 + col >= 0 && col < ncols)
             *reinterpret_cast<uint4 *>(out + (size_t)f * SA_NPTS + n0 + col) =
                 make_uint4(sat_pack2(a.x, a.y), sat_pack2(a.z, a.w), sat_pack2(b.x, b.y), sat_pack2(b.z, b.w));
     }
@@ -436,21 +440,67 @@ __device__ __forceinline__ void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// workgroup barrier that waits for the wave's LDS traffic only (__syncthreads would also wait for the global loads of the
+// tile after next and for the stores of the tile before: exactly what is meant to stay in flight)
+__device__ __forceinline__ void wg_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The helper wave of a cascade wave (same frames, same SIMD): everything that is not the recursion.  A lone wave issues one
+// vector instruction per ~2.5 ns and leaves the rest of its SIMD's turns unused; staging and flushing on the cascade wave
+// itself cost 0.6 instructions per step = 7-9 % of the kernel (filter_q7_kernel<true> 349 -> 325-331 us with this wave,
+// profiles/r4_q15_helper_waves.txt).  During the cascade's tile k the helper windows tile k + 1 into the other half of the
+// input ring, requests tile k + 2 from HBM and flushes the outputs of the tile before -- shifted by the pipeline's eight
+// samples of delay, so that a flush covers exactly one half of the output ring (samples [kTile j - 8, kTile (j+1) - 8) live in
+// slots [kTile j, kTile (j+1)) mod kRing) while the cascade writes the other half.  One workgroup barrier per tile (both sides
+// wait for their LDS traffic only); the cascade side runs nt tiles, the drain, and the same nt + 2 barriers.
+//   flush(j, n0, ncols): store ncols samples starting at sample n0 (may be -8: skipped) from ring slots kTile j ...
+template <typename Flush>
+__device__ __forceinline__ void q15_helper_wave(Flush flush, const int16_t *__restrict__ in, const int16_t *__restrict__ rom,
+                                                int16_t (*tin)[kInPitch], int f0, int batch, int lane, int win_mode, bool idle)
+{
+    constexpr int nt = SA_NPTS / kTile;
+    Q15TileRegs pre;
+    if (!idle) {
+        q15_load_tile(in, rom, f0, batch, 0, lane, pre);
+        q15_window_into_ring(pre, tin, 0, lane, win_mode);
+        q15_load_tile(in, rom, f0, batch, kTile, lane, pre);
+    }
+    wg_lds_sync();
+    for (int k = 0; k <= nt; ++k) {                        // k = nt: the cascade runs its drain
+        if (!idle) {
+            if (k + 1 < nt) q15_window_into_ring(pre, tin, ((k + 1) & 1) * kTile, lane, win_mode);
+            if (k + 2 < nt) q15_load_tile(in, rom, f0, batch, (k + 2) * kTile, lane, pre);
+            if (k >= 1) flush(k - 1, (k - 1) * kTile - 8, kTile);
+        }
+        wg_lds_sync();
+    }
+    if (!idle) flush(nt, nt * kTile - 8, 8);               // the drain's eight samples
+}
 
 template <bool NOB1>
-__global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+__global__ __launch_bounds__(64 * kWgWaves) void filter_q7_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                    int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
 {
     __shared__ __attribute__((aligned(16))) int16_t tin_all[kV2Waves][kFramesPerWave][kInPitch];
     __shared__ __attribute__((aligned(16))) int ring_all[kV2Waves][kFramesPerWave][kRingPitch];     // outputs as dwords
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wid & (kV2Waves - 1);
+    const bool helper = wid >= kV2Waves;                   // wave 4 + w stages and flushes for cascade wave w
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
     int (*ring)[kRingPitch] = ring_all[wave];
     const int fr = lane >> 4;           // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
-    if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
+    constexpr int nt = SA_NPTS / kTile;
+    const bool idle = f0 >= batch;      // a pair without frames still takes part in the workgroup's barriers
+    if (helper) {
+        q15_helper_wave([&](int j, int n0, int ncols) { q7_flush_tile(out, ring, j * kTile, f0, batch, n0, lane, ncols); }, in, rom, tin,
+                        f0, batch, lane, prm.win_mode, idle);
+        return;
+    }
     SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
 
     // taps, pre-shifted by 9; identity = (128 x) >> 7
@@ -489,24 +539,14 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_q7_kernel(const int16_t 
         lds_store16_masked(ring_addr + 4 * (T0 & (kRing - 1)) + 16, vb, out_mask);
     };
 
-    Q15TileRegs pre;
-    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
-    for (int k = 0; k <= SA_NPTS / kTile; ++k) {           // one extra block drains the pipeline
-        const bool live = k < SA_NPTS / kTile;
-        if (live) q15_window_into_ring(pre, tin, (k & 1) * kTile, lane, prm.win_mode);
-        wave_lds_sync();
-        // the next tile's HBM reads fly while this tile is being filtered
-        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
-        // refill values of the input shift register: one 16-bit LDS read per lane and group, requested one group
-        // ahead (profiles/r2_pmc_q15.txt: waiting for it, the wave sat in s_waitcnt 27 % of its life).  The last
-        // group of a tile requests the slots after its half of the ring (the other half, or the row's 8-element
-        // pad): a valid address whose value is not used.
+    wg_lds_sync();
+    for (int k = 0; k < nt; ++k) {
         const int i0 = (k & 1) * kTile;
-        if (live) q7_tile<NOB1>(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
-        else group(k * kTile, xrow[i0]);
-        wave_lds_sync();
-        if (k >= 1) q7_flush_tile(out, ring, (k - 1) * kTile + 8, f0, batch, (k - 1) * kTile, lane);
+        if (!idle) q7_tile<NOB1>(y, c, xrow_addr + 2 * i0, ring_addr + 4 * i0, in_mask, out_mask, cB2, cB1, cB0, nA0, nA1, k127);
+        wg_lds_sync();
     }
+    if (!idle) group(nt * kTile, xrow[0]);                  // drains the pipeline: the frame's last eight samples
+    wg_lds_sync();
     SA_Q15_STAMP_END();
 }
 
@@ -623,19 +663,28 @@ __device__ __forceinline__ void w14_tile(W14Carry &c, const W14Taps &t, unsigned
         : "memory", "scc", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
 }
 
-__global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+__global__ __launch_bounds__(64 * kWgWaves) void filter_w14_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
                                                                     int batch, SaQ15Params prm, const int16_t *__restrict__ rom)
 {
     __shared__ __attribute__((aligned(16))) int16_t tin_all[kV2Waves][kFramesPerWave][kInPitch];
     __shared__ __attribute__((aligned(16))) int16_t ring_all[kV2Waves][kFramesPerWave][kRingPitch];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wid & (kV2Waves - 1);
+    const bool helper = wid >= kV2Waves;
     const int lane = threadIdx.x & 63;
     int16_t (*tin)[kInPitch] = tin_all[wave];
     int16_t (*ring)[kRingPitch] = ring_all[wave];
     const int fr = lane >> 4;           // frame slot in this wave
     const int l16 = lane & 15;          // role inside the row: 0 = input, 1..6 = sections 0..5, 7..8 = delay, 9..15 = input
     const int f0 = (blockIdx.x * kV2Waves + wave) * kFramesPerWave;
-    if (f0 >= batch) return;            // whole wave idle (waves only meet at wave-level barriers)
+    constexpr int nt = SA_NPTS / kTile;
+    const bool idle = f0 >= batch;      // a pair without frames still takes part in the workgroup's barriers
+    if (helper) {
+        q15_helper_wave([&](int j, int n0, int ncols) {
+            q15_flush_tile<kRingPitch>(out, ring, (j * kTile) & (kRing - 1), f0, batch, n0, lane, kRing - 1, ncols);
+        }, in, rom, tin, f0, batch, lane, prm.win_mode, idle);
+        return;
+    }
     SA_Q15_STAMP_BEGIN(blockIdx.x * kV2Waves + wave);
 
     W14Taps taps = w14_taps(16384, 0, 0, 0, 0);              // identity: (16384 x + 8192) >> 14 = x exactly
@@ -651,23 +700,15 @@ __global__ __launch_bounds__(64 * kV2Waves) void filter_w14_kernel(const int16_t
     const unsigned xrow_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int16_t *)xrow;
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int16_t *)(&ring[fr][0]);
 
+    // Sample m lives in ring slot (m + 8) mod kRing (lane 8 holds samples T0 - 8 .. T0 - 1 at the end of the group that
+    // starts at step T0).  The drain pass runs one iteration = four groups: the first delivers the frame's last eight
+    // samples, the other three filter whatever the input ring holds into slots that were flushed long ago.
     W14Carry c = {};
-    Q15TileRegs pre;
-    q15_load_tile(in, rom, f0, batch, 0, lane, pre);
-    for (int k = 0; k <= SA_NPTS / kTile; ++k) {           // one extra pass drains the pipeline
-        const bool live = k < SA_NPTS / kTile;
-        if (live) q15_window_into_ring(pre, tin, (k & 1) * kTile, lane, prm.win_mode);
-        wave_lds_sync();
-        // the next tile's HBM reads fly while this tile is being filtered
-        if (k + 1 < SA_NPTS / kTile) q15_load_tile(in, rom, f0, batch, (k + 1) * kTile, lane, pre);
-        // Sample m lives in ring slot (m + 8) mod kRing (lane 8 holds samples T0 - 8 .. T0 - 1 at the end of the group that
-        // starts at step T0).  The drain pass runs one iteration = four groups: the first delivers the frame's last eight
-        // samples, the other three filter whatever the input ring holds into slots that were flushed long ago.
+    wg_lds_sync();
+    for (int k = 0; k <= nt; ++k) {
         const int i0 = (k & 1) * kTile;
-        w14_tile(c, taps, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, live ? kTile / 32 : 1);
-        wave_lds_sync();
-        if (k >= 1)
-            q15_flush_tile<kRingPitch>(out, ring, ((k - 1) * kTile + 8) & (kRing - 1), f0, batch, (k - 1) * kTile, lane, kRing - 1);
+        if (!idle) w14_tile(c, taps, xrow_addr + 2 * i0, ring_addr + 2 * i0, in_mask, out_mask, k < nt ? kTile / 32 : 1);
+        wg_lds_sync();
     }
     SA_Q15_STAMP_END();
 }
@@ -974,7 +1015,7 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
 {
     if (batch <= 0) return hipSuccess;
     const int per_wg = kFramesPerWave * kV2Waves;
-    const dim3 grid_wg((batch + per_wg - 1) / per_wg), block_wg(64 * kV2Waves);
+    const dim3 grid_wg((batch + per_wg - 1) / per_wg), block_wg(64 * kWgWaves);
     if (p.filter == SA_FILTER_NONE) {
         hipExtLaunchKernelGGL(window_q15_kernel, dim3((batch + kFramesPerWave - 1) / kFramesPerWave), dim3(64), 0, stream, ev.start,
                               ev.stop, 0, in, out_time, batch, p, t.rom);
