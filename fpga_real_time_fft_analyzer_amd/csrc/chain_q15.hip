@@ -17,7 +17,7 @@
 #include <type_traits>
 #include "../../include/specan.h"
 
-#if defined(SA_STAMPS) && !defined(SA_Q15_SECOND_TU)
+#if defined(SA_STAMPS)
 // diagnostic build only: per wave {s_memrealtime at start, at end, HW_ID | XCC_ID << 32} (tools/q15_placement.py)
 __device__ unsigned long long *g_q15_stamps = nullptr;
 extern "C" int sa_debug_set_q15_stamps(void *p)
@@ -75,21 +75,17 @@ __device__ __forceinline__ int lo16(unsigned v) { return (int)(short)(v & 0xFFFF
 __device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
 
 // ------------------------------------------------------------------------------------------ IIR
-// Tile size: 256 samples in this file's own build.  chain_q15_t128.hip compiles the integer cascade a second time with
-// 128-sample tiles (SA_Q15_SECOND_TU): a cascade workgroup then holds 24 KiB of LDS instead of 48.75 KiB and fits
-// beside an FFT workgroup AND another cascade -- what overlap mode wants (10.0 vs 9.3 M frames/s at depth 2); the
-// smaller tile costs 4 % when launches run one after the other, which is why both exist.
-#ifndef SA_Q15_TILE
-#define SA_Q15_TILE 256
-#endif
-constexpr int kTile = SA_Q15_TILE;    // samples per staging tile
+// Tile size: 256 samples.  (Round 3 compiled the cascade a second time with 128-sample tiles for overlapped launches -- half
+// the LDS per workgroup, so that two cascades fit beside an FFT workgroup.  With the helper waves the large tiles win at every
+// depth -- 10.4 vs 9.9-10.2 M frames/s at depth 2, profiles/r4_q15_helper_waves.txt -- and the second build is gone.)
+constexpr int kTile = 256;             // samples per staging tile
 constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
 constexpr int kFramesPerWave = 4;      // one frame per 16-lane row (two frames per wave and two waves per SIMD: 1.47 x slower,
                                        // profiles/r4_int_step_rate.txt)
 // moving a tile between memory and LDS: 16 bytes (8 samples) per lane, kTile / 8 lanes per frame row
-constexpr int kTileLanes = kTile / 8;                       // lanes that cover one row of a tile (32; 16 for 128-sample tiles)
+constexpr int kTileLanes = kTile / 8;                       // lanes that cover one row of a tile
 constexpr int kTileRows = 64 / kTileLanes;                  // rows a wave covers per pass
 constexpr int kTilePasses = kFramesPerWave / kTileRows;     // passes over the wave's four frames
 static_assert(kTile % 32 == 0 && kTileLanes <= 64 && kTileRows * kTilePasses == kFramesPerWave, "tile geometry");
@@ -550,7 +546,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void filter_q7_kernel(const int16_t 
     SA_Q15_STAMP_END();
 }
 
-#ifndef SA_Q15_SECOND_TU     // the wide cascade exists with the large tiles only (overlap mode does not pay for it: specan_abi.cpp)
 // ------------------------------------------------------------------------------------------ IIR, wide Q2.14 form
 // Mode 0xA2 (the build's own spec, oracle/specan_oracle.c:or_iir_sos_q14; the six sections scripts/fft_analyzer_gui.py:108-157
 // designs and :1186-1192 cuts down to two): per section, direct form I,
@@ -713,7 +708,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void filter_w14_kernel(const int16_t
     SA_Q15_STAMP_END();
 }
 
-#endif  // !SA_Q15_SECOND_TU
 
 // ------------------------------------------------------------------------------------------ FFT
 
@@ -1005,13 +999,8 @@ __global__ __launch_bounds__(kFftWide, 8) void fft_q15_kernel(const int16_t *__r
 
 }  // namespace
 
-#ifdef SA_Q15_SECOND_TU
-hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                     const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
-#else
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
                                 const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
-#endif
 {
     if (batch <= 0) return hipSuccess;
     const int per_wg = kFramesPerWave * kV2Waves;
@@ -1020,11 +1009,7 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
         hipExtLaunchKernelGGL(window_q15_kernel, dim3((batch + kFramesPerWave - 1) / kFramesPerWave), dim3(64), 0, stream, ev.start,
                               ev.stop, 0, in, out_time, batch, p, t.rom);
     } else if (p.filter == SA_FILTER_WIDE) {
-#ifdef SA_Q15_SECOND_TU
-        return hipErrorInvalidValue;           // not built with the small tiles
-#else
         hipExtLaunchKernelGGL(filter_w14_kernel, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
-#endif
     } else {
         // B1 = 0 in both coefficient sets (wire order b0,b1,b2,a0,a1,a2 per set): the seven-instruction step
         const bool nob1 = p.c12[1] == 0 && p.c12[7] == 0;
@@ -1036,7 +1021,6 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
     return hipGetLastError();
 }
 
-#ifndef SA_Q15_SECOND_TU
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev)
 {
@@ -1049,4 +1033,3 @@ hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch,
     hipExtLaunchKernelGGL(k, grid, block, lds, stream, ev.start, ev.stop, 0, in_time, out_iq, batch, p, t.rom, t.tw, t.twrec);
     return hipGetLastError();
 }
-#endif

@@ -132,8 +132,5 @@ constexpr int kSaTwRecs = 4096 + 1024 + 256;
 
 hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
                                 const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);
-// the same cascade with 128-sample tiles (chain_q15_t128.hip): for launches that overlap (half the LDS per workgroup)
-hipError_t sa_launch_filter_q15_t128(const int16_t *in, int16_t *out_time, int batch, const SaQ15Params &p,
-                                     const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);
 hipError_t sa_launch_fft_q15(const int16_t *in_time, int16_t *out_iq, int batch, bool apply_window,
                              const SaQ15Params &p, const SaQ15Tables &t, hipStream_t stream, SaLaunchEv ev);

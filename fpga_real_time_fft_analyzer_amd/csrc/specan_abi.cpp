@@ -1267,23 +1267,16 @@ int sa_process_q15(sa_handle *h, const int16_t *in, int16_t *out_iq, int batch, 
         return end_call(h, c);
     }
     { const int rc = ensure_work(h, c.slot, batch, c.captured); if (rc != SA_OK) return rc; }
-    // two launches in flight take the cascade with 128-sample tiles: a second cascade then fits a CU's LDS beside the first
-    // one and an FFT workgroup (measured: 10.0 vs 9.3 M frames/s at depth 2; at depth 3 the 256-sample tiles are ahead,
-    // 9.6 vs 9.3, and stream-ordered by 4 %: tools/q15_overlap_depth.py).
-    // The WIDE cascade is the exception (round 4, tools/q15_overlap_modes.py, profiles/r4_soak_and_wide_overlap.txt): its step
-    // is made of packed dot products, the integer FFT's twiddle products are too, and side by side the two starve each other --
-    // 6.2 M frames/s at depth 2 with the small tiles, 7.0 M with the large ones, against 7.4 M stream-ordered; a raised wave
-    // priority and the Q7 kernels' register allocation change nothing.  It keeps the large tiles, and at depth 2 its cascade
-    // waits for the previous call of the handle (7.2 M; at depth 3 it runs free: 7.5-7.9 M).
+    // The WIDE cascade does not gain from overlapped launches (tools/q15_overlap_modes.py, profiles/r4_q15_helper_waves.txt):
+    // its step is made of packed dot products, the integer FFT's twiddle products are too, and side by side the two starve
+    // each other -- 7.5-7.9 M frames/s at depth 2 when left free against 8.3 M stream-ordered.  At depth 2 its cascade
+    // therefore waits for the previous call of the handle (8.0 M; at depth 3 it runs free: 7.9-8.2 M).
     const bool wide = p.filter == SA_FILTER_WIDE;
     if (c.overlapped && wide && h->overlap == 2) {
         const int prev = (c.slot + h->overlap - 1) % h->overlap;
         if (h->ov_used[prev]) SA_HIP(h, hipStreamWaitEvent(c.stream, h->ov_done[prev], 0));
     }
-    const bool small_tiles = c.overlapped && h->overlap == 2 && !wide;
-    SA_HIP(h, small_tiles
-                  ? sa_launch_filter_q15_t128(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr})
-                  : sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr}));
+    SA_HIP(h, sa_launch_filter_q15(in, h->d_work[c.slot], batch, p, t, c.stream, {c.start, nullptr}));
     SA_HIP(h, sa_launch_fft_q15(h->d_work[c.slot], out_iq, batch, false, p, t, c.stream, {nullptr, c.stop}));
     return end_call(h, c);
 }

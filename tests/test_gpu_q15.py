@@ -273,7 +273,7 @@ def test_custom_rom_and_window_modes(ch, torch_mod, oracle):
             assert np.array_equal(ch.process_q15(_dev(torch_mod, xf)).cpu().numpy(), ref), (wm, cmd)
     # The same corner through the staging of the cascade kernels (the tests above reach it through the FFT-side window only):
     # a ROM whose -32768 entries sit in a few tiles, full-scale samples with -32768 at those very positions and at others,
-    # all three cascade kernels, the 256- and the 128-sample-tile builds (depth 2), time series and frames
+    # all three cascade kernels, stream-ordered and with two launches in flight, time series and frames
     rom2 = rng.integers(-32767, 32768, size=N).astype(np.int16)
     hot = np.concatenate([np.arange(100, 130), np.arange(5000, 5003), np.arange(8191, 8194), np.arange(16380, 16384)])
     rom2[hot] = -32768
