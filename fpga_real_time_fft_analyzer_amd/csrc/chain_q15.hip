@@ -79,7 +79,6 @@ __device__ __forceinline__ int hi16(unsigned v) { return (int)v >> 16; }
 // the LDS per workgroup, so that two cascades fit beside an FFT workgroup.  With the helper waves the large tiles win at every
 // depth -- 10.4 vs 9.9-10.2 M frames/s at depth 2, profiles/r4_q15_helper_waves.txt -- and the second build is gone.)
 constexpr int kTile = 256;             // samples per staging tile
-constexpr int kRowPitch = kTile + 8;  // int16 elements; rows stay 16-byte aligned, 8 rows land on distinct banks
 constexpr int kRing = 2 * kTile;      // output ring per frame: the pipeline delivers sample T - 5 at step T
 constexpr int kRingPitch = kRing + 8;
 constexpr int kFramesPerWave = 4;      // one frame per 16-lane row (two frames per wave and two waves per SIMD: 1.47 x slower,
@@ -97,9 +96,9 @@ static_assert(kTile % 32 == 0 && kTileLanes <= 64 && kTileRows * kTilePasses == 
 // The taps are held pre-shifted by 9: floor(c v / 128) mod 2^16 is then bits 16..31 of the 32-bit product
 // v * (c << 9) (exact: only bits above 31 are lost), i.e. its high word, which the SDWA form of v_add_u32
 // reads in place -- no shift instructions -- and whose last add sign-extends the 16-bit result on write.
-// The products are v_mul_i32_i24 / v_mad_i32_i24 (full rate; samples are 16-bit, shifted taps 17-bit).
+// The products are v_mul_i32_i24 / v_mad_i32_i24 (samples are 16-bit, shifted taps 17-bit: both fit the 24-bit operands).
 
-// window + stage one tile of 8 frames x 256 samples into LDS (16 B per lane, two rows per instruction)
+// one tile of the wave's four frames (and the matching ROM words) on its way from HBM to the input ring: 16 B per lane and pass
 struct Q15TileRegs {
     uint4 x[kTilePasses];
     uint4 c[kTilePasses];
@@ -118,39 +117,6 @@ __device__ __forceinline__ void q15_load_tile(const int16_t *__restrict__ in, co
         if (f < batch) r.x[i] = *reinterpret_cast<const uint4 *>(in + (size_t)f * SA_NPTS + n0 + col);
         r.c[i] = *reinterpret_cast<const uint4 *>(rom + n0 + col);
     }
-}
-
-// window the loaded tile and put it into LDS
-__device__ __forceinline__ void q15_store_tile(const Q15TileRegs &r, int16_t (*tin)[kRowPitch], int lane, int win_mode)
-{
-#pragma unroll
-    for (int i = 0; i < kTilePasses; ++i) {
-        const int row = kTileRows * i + lane / kTileLanes;
-        const int col = (lane % kTileLanes) * 8;
-        const unsigned xs[4] = {r.x[i].x, r.x[i].y, r.x[i].z, r.x[i].w};
-        const unsigned cs[4] = {r.c[i].x, r.c[i].y, r.c[i].z, r.c[i].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int a, b;
-            if (win_mode == SA_WIN_RTL_SIGNED) {
-                a = win_rtl(lo16(xs[k]), lo16(cs[k]));
-                b = win_rtl(hi16(xs[k]), hi16(cs[k]));
-            } else {
-                a = win_u16(lo16(xs[k]), lo16(cs[k]));
-                b = win_u16(hi16(xs[k]), hi16(cs[k]));
-            }
-            *reinterpret_cast<unsigned *>(&tin[row][col + 2 * k]) = pack2(a, b);
-        }
-    }
-}
-
-__device__ __forceinline__ void q15_stage_tile(const int16_t *__restrict__ in, const int16_t *__restrict__ rom,
-                                               int16_t (*tin)[kRowPitch], int f0, int batch, int n0, int lane,
-                                               int win_mode)
-{
-    Q15TileRegs r;
-    q15_load_tile(in, rom, f0, batch, n0, lane, r);
-    q15_store_tile(r, tin, lane, win_mode);
 }
 
 template <int PITCH>
@@ -172,20 +138,32 @@ __device__ __forceinline__ void q15_flush_tile(int16_t *__restrict__ out, const 
     }
 }
 
-// Window only (filter mode 0xB1 through sa_filter_q15: the windowed time series, new/hann8192.vhd:36-39): one wave =
-// 4 frames, a tile at a time through LDS.
-__global__ __launch_bounds__(64) void window_q15_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, int batch,
-                                                         SaQ15Params prm, const int16_t *__restrict__ rom)
+// Window only (filter mode 0xB1 through sa_filter_q15: the windowed time series, new/hann8192.vhd:36-39): element-wise,
+// 16 bytes (eight samples) of a frame per thread, the ROM words from the L2.
+constexpr int kWinThreads = 256;
+__global__ __launch_bounds__(kWinThreads) void window_q15_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, int batch,
+                                                                  SaQ15Params prm, const int16_t *__restrict__ rom)
 {
-    __shared__ __attribute__((aligned(16))) int16_t tin[kFramesPerWave][kRowPitch];
-    const int lane = threadIdx.x;
-    const int f0 = blockIdx.x * kFramesPerWave;
-    for (int n0 = 0; n0 < SA_NPTS; n0 += kTile) {
-        q15_stage_tile(in, rom, tin, f0, batch, n0, lane, prm.win_mode);
-        __syncthreads();
-        q15_flush_tile<kRowPitch>(out, tin, 0, f0, batch, n0, lane);
-        __syncthreads();
+    const size_t chunk = (size_t)blockIdx.x * kWinThreads + threadIdx.x;       // 16-byte chunk of the batch
+    if (chunk >= (size_t)batch * (SA_NPTS / 8)) return;
+    const int col = (int)(chunk % (SA_NPTS / 8)) * 8;
+    const uint4 xv = *reinterpret_cast<const uint4 *>(in + chunk * 8);
+    const uint4 cv = *reinterpret_cast<const uint4 *>(rom + col);
+    const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w};
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int a, b;
+        if (prm.win_mode == SA_WIN_RTL_SIGNED) {
+            a = win_rtl(lo16(xs[q]), lo16(cs[q]));
+            b = win_rtl(hi16(xs[q]), hi16(cs[q]));
+        } else {
+            a = win_u16(lo16(xs[q]), lo16(cs[q]));
+            b = win_u16(hi16(xs[q]), hi16(cs[q]));
+        }
+        o[q] = pack2(a, b);
     }
+    *reinterpret_cast<uint4 *>(out + chunk * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------ IIR, Q7 (FPGA-exact)
@@ -1006,8 +984,9 @@ hipError_t sa_launch_filter_q15(const int16_t *in, int16_t *out_time, int batch,
     const int per_wg = kFramesPerWave * kV2Waves;
     const dim3 grid_wg((batch + per_wg - 1) / per_wg), block_wg(64 * kWgWaves);
     if (p.filter == SA_FILTER_NONE) {
-        hipExtLaunchKernelGGL(window_q15_kernel, dim3((batch + kFramesPerWave - 1) / kFramesPerWave), dim3(64), 0, stream, ev.start,
-                              ev.stop, 0, in, out_time, batch, p, t.rom);
+        const size_t chunks = (size_t)batch * (SA_NPTS / 8);
+        hipExtLaunchKernelGGL(window_q15_kernel, dim3((unsigned)((chunks + kWinThreads - 1) / kWinThreads)), dim3(kWinThreads), 0, stream,
+                              ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
     } else if (p.filter == SA_FILTER_WIDE) {
         hipExtLaunchKernelGGL(filter_w14_kernel, grid_wg, block_wg, 0, stream, ev.start, ev.stop, 0, in, out_time, batch, p, t.rom);
     } else {
