@@ -6,12 +6,13 @@
 //                      oracle/specan_oracle.c:or_iir_sos_q14).  Both recursions are non-linear (per-product
 //                      truncation and 16-bit wrap; rounding and saturation), so a frame cannot be cut in
 //                      time; the parallelism is batch x section: one frame per 16-lane DPP row, the six sections a
-//                      systolic pipeline along the lanes (lane s works on sample n-s).
+//                      systolic pipeline along the lanes (lane s works on sample n-s).  One cascade wave per SIMD
+//                      (a lone wave: one instruction per ~2.5 ns), one helper wave beside it for staging and flushing.
 //   sa_fft kernel    : SA-FXFFT-1, the fixed-point FFT that stands where ip/xfft_0 stands
-//                      (radix-4 DIF, >>2 per stage, Q15 twiddles, truncation).  One 256-thread
+//                      (radix-4 DIF, >>2 per stage, Q15 twiddles, truncation).  One 1024-thread
 //                      workgroup per frame, data in LDS as packed (re,im) int16 pairs, Stockham
-//                      (autosort) addressing so the result is in natural order; the arithmetic per
-//                      butterfly is exactly oracle/specan_oracle.c:or_fxfft16k.
+//                      (autosort) addressing so the result is in natural order, stages paired in registers; the
+//                      arithmetic per butterfly is exactly oracle/specan_oracle.c:or_fxfft16k.
 #include "sa_common.hpp"
 #include <cstdlib>
 #include <type_traits>
