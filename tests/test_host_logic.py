@@ -339,3 +339,117 @@ def test_wide_step_split_accumulators_are_exact():
     assert np.abs(part_l).max() < 2 ** 31 and np.abs(part_h).max() < 2 ** 31      # no partial sum wraps
     acc = (eff * v).sum(axis=1)
     assert np.array_equal((acc + 8192) >> 14, part_h[:, -1] + (part_l[:, -1] >> 14))
+
+
+def test_fft_q15_paired_stage_addressing():
+    """The index arithmetic of fft_q15_kernel (csrc/chain_q15.hip) restated in numpy on complex doubles: stage 0 from
+    the input, the register passes (1,2), (3,4), (5,6) with their thread-to-butterfly maps, twiddle exponents, output
+    positions and the two XOR swizzles.  With exact arithmetic the result must be the DFT in natural order, and every
+    swizzled LDS access of a wave must touch 64 different banks."""
+    rng = np.random.default_rng(5)
+    n = 16384
+    x = rng.standard_normal(n)
+    W = np.exp(-2j * np.pi * np.arange(n) / n)
+
+    def bf4(a, b, c, d, e):                                  # radix-4 DIF butterfly, outputs i' twiddled by W^(i' e)
+        o = [a + b + c + d, a - 1j * b - c + 1j * d, a - b + c - d, a + 1j * b - c - 1j * d]
+        return [o[i] * W[(i * e) % n] for i in range(4)]
+
+    t = np.arange(1024)
+    lane, wave = t & 63, t >> 6
+
+    def banks_distinct(addr):                                # [1024] word addresses of one wave instruction per 64 lanes
+        return all(len(set((addr[w * 64:(w + 1) * 64] & 63).tolist())) == 64 for w in range(16))
+
+    buf = np.zeros(n, complex)
+    for u in range(4):                                       # stage 0: bf = t + 1024 u, outputs at 4 bf + i'
+        bf = t + 1024 * u
+        o = bf4(x[bf], x[bf + 4096], x[bf + 8192], x[bf + 12288], bf)
+        for i in range(4):
+            buf[4 * bf + i] = o[i]
+    # pass (1,2)
+    v = [buf[t + 1024 * m] for m in range(16)]
+    xx = [None] * 16
+    for u in range(4):
+        e1 = ((t + 1024 * u) >> 2) << 2
+        o = bf4(v[u], v[u + 4], v[u + 8], v[u + 12], e1)
+        for i in range(4):
+            xx[4 * i + u] = o[i]
+    j2 = (t >> 2) & 255
+    ob = ((j2 << 6) | (t & 3)) ^ ((j2 & 15) << 2)
+    buf2 = np.zeros(n, complex)
+    plain = np.zeros(n, complex)                             # the same without the swizzle: Stockham order after three stages
+    for ip in range(4):
+        o = bf4(xx[4 * ip], xx[4 * ip + 1], xx[4 * ip + 2], xx[4 * ip + 3], j2 << 4)
+        for i in range(4):
+            addr = ob ^ ((4 * i + ip) << 2)
+            assert banks_distinct(addr)
+            buf2[addr] = o[i]
+            plain[(j2 << 6) | (i << 4) | (ip << 2) | (t & 3)] = o[i]
+    # pass (3,4)
+    for m in range(16):
+        addr = (t + 1024 * m) ^ (wave << 2)
+        assert banks_distinct(addr)
+        assert np.array_equal(buf2[addr], plain[t + 1024 * m])
+    v = [buf2[(t + 1024 * m) ^ (wave << 2)] for m in range(16)]
+    for u in range(4):
+        o = bf4(v[u], v[u + 4], v[u + 8], v[u + 12], (wave + 16 * u) << 6)
+        for i in range(4):
+            xx[4 * i + u] = o[i]
+    buf3 = np.zeros(n, complex)
+    for ip in range(4):
+        o = bf4(xx[4 * ip], xx[4 * ip + 1], xx[4 * ip + 2], xx[4 * ip + 3], wave << 8)
+        for i in range(4):
+            addr = (wave << 10) | ((4 * i + ip) << 6) | lane
+            assert banks_distinct(addr)
+            buf3[addr] = o[i]
+    # pass (5,6)
+    v = [buf3[t + 1024 * m] for m in range(16)]
+    w = [None] * 16
+    for u in range(4):
+        o = bf4(v[u], v[u + 4], v[u + 8], v[u + 12], u * 1024)
+        for i in range(4):
+            w[4 * u + i] = o[i]
+    out = np.zeros(n, complex)
+    for u in range(4):
+        o = bf4(w[u], w[u + 4], w[u + 8], w[u + 12], 0)
+        for i in range(4):
+            out[t + 1024 * (u + 4 * i)] = o[i]
+    ref = np.fft.fft(x)
+    assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_cascade_helper_wave_schedule():
+    """The hand-over between a cascade wave and its helper wave (csrc/chain_q15.hip: q15_helper_wave), interval by interval
+    between workgroup barriers: within an interval the two waves never touch the same half of either ring, a flush only
+    reads samples the cascade wrote in an EARLIER interval, and the flushes cover every sample of the frame exactly once."""
+    tile, ring, nt, n = 256, 512, 64, 16384
+    slot = lambda m: (m + 8) % ring                          # sample m lives in ring slot (m + 8) mod kRing
+    written_in = {}                                          # sample -> interval in which the cascade stored it
+    flushed = []
+    for k in range(nt + 1):                                  # interval k: cascade tile k (k = nt: the drain group)
+        if k < nt:
+            cas_samples = range(k * tile - 8, (k + 1) * tile - 8)
+            cas_in_half = k & 1                              # input ring half the cascade reads
+        else:
+            cas_samples = range(nt * tile - 8, nt * tile)    # the drain's first group: the frame's last eight samples
+            cas_in_half = None
+        cas_slots = {slot(m) for m in cas_samples}
+        hlp_in_half = (k + 1) & 1 if k + 1 < nt else None    # input ring half the helper windows the next tile into
+        if cas_in_half is not None and hlp_in_half is not None:
+            assert cas_in_half != hlp_in_half
+        if k >= 1:                                           # helper flushes samples [(k-1) tile - 8, k tile - 8)
+            fl = range((k - 1) * tile - 8, k * tile - 8)
+            fl_slots = {(((k - 1) * tile) + c) % ring for c in range(tile)}
+            assert fl_slots == {slot(m) for m in fl}
+            assert not (fl_slots & cas_slots)
+            for m in fl:
+                if m >= 0:
+                    assert written_in[m] < k
+                    flushed.append(m)
+        for m in cas_samples:
+            written_in[m] = k
+    tail = range(nt * tile - 8, nt * tile)                   # after the last barrier: eight samples from slots 0..7
+    assert {slot(m) for m in tail} == set(range(8)) and all(written_in[m] == nt for m in tail)
+    flushed += list(tail)
+    assert sorted(flushed) == list(range(n))
