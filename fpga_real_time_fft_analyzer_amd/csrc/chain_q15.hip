@@ -835,7 +835,7 @@ __device__ __forceinline__ void fx_butterfly_real(int a, int b, int c, int d, ui
 // per SIMD, a quarter of a wave's life in s_waitcnt behind a barrier with one other wave to cover: 192 us.  Rounds 2-3 ran
 // 1024 threads with ONE stage per LDS exchange for stages 0..4: 155-158 us.  Pairing the stages (three exchanges instead
 // of five, the second stage of a pair shares one twiddle triple among a thread's four butterflies) and reading a lane's
-// three twiddles as one 32-byte record instead of three strided gathers: 126-130 us, profiles/r4_fft_q15_passes.txt.)
+// three twiddles as one 32-byte record instead of three strided gathers: 126-137 us by box, profiles/r4_fft_q15_passes.txt.)
 //   7 radix-4 DIF stages, Stockham addressing:
 //   storage after s stages: pos = j * 4^s + kappa   (j: remaining time index, kappa: bins so far)
 //   butterfly bf in [0,4096): j' = bf >> 2s, kappa = bf & (4^s - 1); inputs at bf + i*4096;
